@@ -1,0 +1,169 @@
+/*
+ * nerf_kinematics.h -- C ABI of the MI355X (gfx950) NeRF volume-rendering path.
+ *
+ * The reference project (tomeupm/nerf-kinematics) has no FFI or plugin interface for this
+ * path: its renderer is Python code in an un-vendored nerf-pytorch submodule
+ * (/root/reference/.gitmodules:10-12) that calls PyTorch tensor ops.  The boundary replaced here
+ * is therefore the function contract of that code's `render_rays` (README.md:90-93 shows the
+ * only call site, `python run_nerf.py --config ...`), parameterised by the `nerf.train` /
+ * `nerf.validation` blocks of the experiment files
+ * (/root/reference/trained_models/nerf-pytorch/lego-lowres3/config.yml:46-63) and the `models`
+ * block (config.yml:18-42).  Each entry point below names the stage of that code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed for the call unless the comment says "host";
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream), allocates nothing and keeps no global state besides an error string;
+ *   - return value: NK_OK or a negative nk_status; nk_last_error() gives the text (per thread);
+ *   - parameters of a network are ONE flat fp32 array in the state-dict order of the lineage
+ *     (see nk_arch.lineage); gradients use the same layout.
+ */
+#ifndef NERF_KINEMATICS_H
+#define NERF_KINEMATICS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum nk_status {
+    NK_OK = 0,
+    NK_ERR_ARG = -1,          /* null pointer, non-positive size, misaligned buffer */
+    NK_ERR_UNSUPPORTED = -2,  /* network shape / sample count outside the compiled kernels */
+    NK_ERR_HIP = -3,          /* a HIP call or launch failed */
+    NK_ERR_WORKSPACE = -4     /* workspace smaller than nk_render_workspace_bytes() */
+} nk_status;
+
+/* Network lineages (parameter order and activation placement):
+ *   NK_LINEAGE_RUN_NERF  pts_linears.0..D-1 (ReLU each; layer skip+1 takes cat[gamma(x), h]),
+ *                        views_linears.0, feature_linear, alpha_linear, rgb_linear
+ *   NK_LINEAGE_FLEXIBLE  layer1, layers_xyz.0..D-2, layers_dir.0, fc_alpha, fc_rgb, fc_feat
+ *                        (the key order of checkpoint110000.ckpt in
+ *                        /root/reference/trained_models/nerf-pytorch/lego-lowres3/)            */
+enum { NK_LINEAGE_RUN_NERF = 0, NK_LINEAGE_FLEXIBLE = 1 };
+
+/* models.coarse / models.fine of config.yml:18-42 */
+typedef struct nk_arch {
+    int32_t depth;       /* trunk layers D, first layer included            (8 | 4)   */
+    int32_t width;       /* trunk width W                                   (256 | 128) */
+    int32_t skip;        /* trunk layer skip+1 takes cat[gamma(x), h]; -1 = none (4 | -1) */
+    int32_t dir_width;   /* hidden width of the view-direction branch       (128 | 64) */
+    int32_t n_freq_xyz;  /* num_encoding_fn_xyz, <= 10                                 */
+    int32_t n_freq_dir;  /* num_encoding_fn_dir, <= 4                                  */
+    int32_t relu_first;  /* ReLU after the first trunk layer                           */
+    int32_t relu_feat;   /* ReLU after the feature layer                               */
+    int32_t lineage;     /* NK_LINEAGE_*                                               */
+} nk_arch;
+
+/* nerf.train / nerf.validation of config.yml:46-63 */
+typedef struct nk_render_opts {
+    int32_t num_coarse;
+    int32_t num_fine;             /* 0: coarse pass only                                  */
+    int32_t perturb;              /* stratified jitter + random u in sample_pdf           */
+    int32_t lindisp;
+    int32_t white_background;
+    float   radiance_field_noise_std;
+    uint32_t seed;                /* seed of the counter-based RNG streams                */
+} nk_render_opts;
+
+/* Camera for nk_get_rays: intrinsics as in transforms.json (fl_x, fl_y, cx, cy) and a 3x4
+ * camera-to-world matrix, row major.  Blender/OpenGL convention.                            */
+typedef struct nk_camera {
+    int32_t H, W;
+    float fx, fy, cx, cy;
+    float c2w[12];
+    float near, far;
+    int32_t ndc;                  /* forward-facing NDC warp (dataset.no_ndc: false)      */
+    float ndc_near;               /* near plane of the warp, 1.0 in nerf-pytorch          */
+} nk_camera;
+
+/* Outputs of render_rays.  rgb: [R,3]; the others [R].  *_coarse may be NULL when unwanted;
+ * *_fine must be NULL when num_fine == 0.                                                  */
+typedef struct nk_render_out {
+    float *rgb_fine, *disp_fine, *acc_fine, *depth_fine;
+    float *rgb_coarse, *disp_coarse, *acc_coarse, *depth_coarse;
+} nk_render_out;
+
+int nk_version(void);
+const char* nk_last_error(void);
+
+/* ---- model ------------------------------------------------------------------------------ */
+/* Number of fp32 parameters of `arch` (weights and biases), or a negative nk_status.        */
+int64_t nk_num_params(const nk_arch* arch);
+/* Bytes of the bf16 MFMA-fragment image of one network (forward + transposed streams).      */
+int64_t nk_packed_bytes(const nk_arch* arch);
+/* fp32 master parameters -> bf16 fragment streams consumed by the MLP kernels.
+ * Replaces nothing in the reference (torch keeps fp32 nn.Linear weights); call after every
+ * optimiser step.                                                                           */
+int nk_pack_weights(const nk_arch* arch, const float* params, void* packed, void* stream);
+
+/* ---- stages (each replaces one function of the nerf-pytorch render path) ------------------ */
+/* get_rays + ndc_rays + ray-batch assembly: rows [o(3) d(3) near far viewdir(3)] (11 floats).
+ * pixel_idx: R flat pixel indices (row*W+col) or NULL for pixels first_pixel..first_pixel+R-1 */
+int nk_get_rays(const nk_camera* cam /*host*/, const int32_t* pixel_idx, int64_t first_pixel,
+                int64_t R, float* ray_batch, void* stream);
+/* Coarse depths: linspace in depth or disparity + stratified jitter (render_rays, first part) */
+int nk_stratified_z(const float* ray_batch, int64_t R, const nk_render_opts* opts, float* z,
+                    void* stream);
+/* Embedder + NeRF.forward for n samples per ray: raw[R,n,4] = (rgb_raw, sigma_raw).
+ * act_save: NULL (inference) or nk_act_bytes() bytes receiving the activations for backward. */
+int64_t nk_act_bytes(const nk_arch* arch, int64_t R, int32_t n);
+int nk_mlp_forward(const nk_arch* arch, const void* packed, const float* ray_batch,
+                   const float* z, int64_t R, int32_t n, float* raw, void* act_save,
+                   void* stream);
+/* raw2outputs.  noise_stream: RNG stream id of the sigma noise (2 coarse, 3 fine).
+ * Any of disp/acc/depth/weights may be NULL.                                                */
+int nk_raw2outputs(const float* raw, const float* z, const float* ray_batch, int64_t R,
+                   int32_t n, const nk_render_opts* opts, int32_t noise_stream, float* rgb,
+                   float* disp, float* acc, float* depth, float* weights, void* stream);
+/* sample_pdf on the interior coarse weights + sort(cat[z, z_samples]) -> z_all[R,Nc+Nf].
+ * z_samples (optional) receives the unsorted new samples [R,Nf].                            */
+int nk_sample_pdf(const float* z_coarse, const float* weights, int64_t R,
+                  const nk_render_opts* opts, float* z_all, float* z_samples, void* stream);
+/* Backward of raw2outputs w.r.t. raw, given d(loss)/d(rgb_map) [R,3] (d_acc, d_depth optional,
+ * NULL = zero).  The sample_pdf inputs are detached, as in the reference.                   */
+int nk_raw2outputs_bwd(const float* raw, const float* z, const float* ray_batch, int64_t R,
+                       int32_t n, const nk_render_opts* opts, int32_t noise_stream,
+                       const float* d_rgb, const float* d_acc, const float* d_depth,
+                       float* d_raw, void* stream);
+/* Backward of the MLP: grad (flat fp32, same layout as params) += dL/dparams.
+ * dz_scratch: nk_dz_bytes() bytes of scratch.                                               */
+int64_t nk_dz_bytes(const nk_arch* arch, int64_t R, int32_t n);
+int nk_mlp_backward(const nk_arch* arch, const void* packed, const void* act_save,
+                    const float* d_raw, int64_t R, int32_t n, void* dz_scratch, float* grad,
+                    void* stream);
+/* img2mse on both maps: loss[0] += mean((rgb-target)^2) for each non-NULL rgb; d_rgb = its
+ * gradient times grad_scale.                                                                */
+int nk_mse_loss(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t R,
+                float grad_scale, float* loss, float* d_rgb_coarse, float* d_rgb_fine,
+                void* stream);
+/* torch.optim.Adam update (the optimiser stored in the reference checkpoints) on flat buffers */
+int nk_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                 void* stream);
+
+/* ---- render_rays -------------------------------------------------------------------------- */
+/* Workspace for R rays; `training` != 0 adds the activation and gradient scratch.           */
+int64_t nk_render_workspace_bytes(const nk_arch* coarse, const nk_arch* fine,
+                                  const nk_render_opts* opts, int64_t R, int training);
+/* render_rays forward: stratified z -> coarse MLP -> raw2outputs -> sample_pdf -> fine MLP ->
+ * raw2outputs.  packed_fine / arch_fine may be NULL when opts->num_fine == 0.               */
+int nk_render_rays_fwd(const nk_arch* arch_coarse, const void* packed_coarse,
+                       const nk_arch* arch_fine, const void* packed_fine,
+                       const float* ray_batch, int64_t R, const nk_render_opts* opts,
+                       int training, void* workspace, int64_t workspace_bytes,
+                       const nk_render_out* out, void* stream);
+/* render_rays backward from d(loss)/d(rgb_fine), d(loss)/d(rgb_coarse) (either may be NULL).
+ * Must follow nk_render_rays_fwd(training=1) on the same workspace.  grad_* accumulate.     */
+int nk_render_rays_bwd(const nk_arch* arch_coarse, const void* packed_coarse,
+                       const nk_arch* arch_fine, const void* packed_fine,
+                       const float* ray_batch, int64_t R, const nk_render_opts* opts,
+                       void* workspace, int64_t workspace_bytes, const float* d_rgb_fine,
+                       const float* d_rgb_coarse, float* grad_coarse, float* grad_fine,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_KINEMATICS_H */

@@ -1,0 +1,116 @@
+// render_rays forward / backward: the stage kernels chained on one stream over a caller-owned
+// workspace.  Mirrors the body of nerf-pytorch's render_rays (coarse pass, sample_pdf, fine pass)
+// with the knobs of the nerf.train / nerf.validation blocks of the reference experiment files
+// (/root/reference/trained_models/nerf-pytorch/lego-lowres3/config.yml:46-63).
+#include <string.h>
+#include "nk_common.h"
+
+namespace {
+
+struct WsLayout {
+    int64_t z_c, raw_c, w_c, rgb_c_tmp, z_all, raw_f, act_c, act_f, d_raw, dz, total;
+};
+
+inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+int layout(const nk_arch* ac, const nk_arch* af, const nk_render_opts* o, int64_t R, int training, WsLayout* L) {
+    if (!ac || !o || R <= 0) NK_FAIL(NK_ERR_ARG, "render workspace: null pointer or R <= 0");
+    const int Nc = o->num_coarse, Nf = o->num_fine, N = Nc + Nf;
+    if (Nc < 2 || Nf < 0) NK_FAIL(NK_ERR_ARG, "render workspace: num_coarse=%d num_fine=%d", Nc, Nf);
+    if (Nf > 0 && !af) NK_FAIL(NK_ERR_ARG, "render workspace: num_fine > 0 needs a fine network");
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { int64_t at = off; off = align256(off + bytes); return at; };
+    L->z_c = take(R * Nc * 4);
+    L->raw_c = take(R * Nc * 16);
+    L->w_c = take(R * Nc * 4);
+    L->rgb_c_tmp = take(R * 12);
+    L->z_all = L->raw_f = L->act_c = L->act_f = L->d_raw = L->dz = -1;
+    if (Nf > 0) { L->z_all = take(R * N * 4); L->raw_f = take(R * N * 16); }
+    if (training) {
+        int64_t b = nk_act_bytes(ac, R, Nc);
+        if (b < 0) return (int)b;
+        L->act_c = take(b);
+        int64_t dzb = nk_dz_bytes(ac, R, Nc);
+        if (dzb < 0) return (int)dzb;
+        if (Nf > 0) {
+            b = nk_act_bytes(af, R, N);
+            if (b < 0) return (int)b;
+            L->act_f = take(b);
+            const int64_t d2 = nk_dz_bytes(af, R, N);
+            if (d2 < 0) return (int)d2;
+            if (d2 > dzb) dzb = d2;
+        }
+        L->d_raw = take(R * (Nf > 0 ? N : Nc) * 16);
+        L->dz = take(dzb);
+    }
+    L->total = off;
+    return NK_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t nk_render_workspace_bytes(const nk_arch* coarse, const nk_arch* fine, const nk_render_opts* opts,
+                                             int64_t R, int training) {
+    WsLayout L;
+    int rc = layout(coarse, fine, opts, R, training, &L);
+    return rc < 0 ? rc : L.total;
+}
+
+extern "C" int nk_render_rays_fwd(const nk_arch* ac, const void* pc, const nk_arch* af, const void* pf,
+                                  const float* ray_batch, int64_t R, const nk_render_opts* o, int training,
+                                  void* workspace, int64_t workspace_bytes, const nk_render_out* out, void* stream) {
+    if (!ac || !pc || !ray_batch || !o || !workspace || !out) NK_FAIL(NK_ERR_ARG, "nk_render_rays_fwd: null pointer");
+    if (((uintptr_t)workspace & 255) != 0) NK_FAIL(NK_ERR_ARG, "nk_render_rays_fwd: workspace must be 256-byte aligned");
+    WsLayout L;
+    int rc = layout(ac, af, o, R, training, &L);
+    if (rc < 0) return rc;
+    if (workspace_bytes < L.total)
+        NK_FAIL(NK_ERR_WORKSPACE, "nk_render_rays_fwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)L.total);
+    const int Nc = o->num_coarse, Nf = o->num_fine, N = Nc + Nf;
+    if (Nf > 0 && (!pf || !out->rgb_fine)) NK_FAIL(NK_ERR_ARG, "nk_render_rays_fwd: num_fine > 0 needs packed_fine and rgb_fine");
+    if (Nf == 0 && !out->rgb_coarse) NK_FAIL(NK_ERR_ARG, "nk_render_rays_fwd: coarse-only render needs rgb_coarse");
+    char* ws = (char*)workspace;
+    float* z_c = (float*)(ws + L.z_c); float* raw_c = (float*)(ws + L.raw_c); float* w_c = (float*)(ws + L.w_c);
+    float* rgb_c = out->rgb_coarse ? out->rgb_coarse : (float*)(ws + L.rgb_c_tmp);
+
+    if ((rc = nk_stratified_z(ray_batch, R, o, z_c, stream)) < 0) return rc;
+    if ((rc = nk_mlp_forward(ac, pc, ray_batch, z_c, R, Nc, raw_c, training ? ws + L.act_c : nullptr, stream)) < 0) return rc;
+    if ((rc = nk_raw2outputs(raw_c, z_c, ray_batch, R, Nc, o, NK_STREAM_NOISE_COARSE, rgb_c, out->disp_coarse,
+                             out->acc_coarse, out->depth_coarse, w_c, stream)) < 0) return rc;
+    if (Nf > 0) {
+        float* z_all = (float*)(ws + L.z_all); float* raw_f = (float*)(ws + L.raw_f);
+        if ((rc = nk_sample_pdf(z_c, w_c, R, o, z_all, nullptr, stream)) < 0) return rc;
+        if ((rc = nk_mlp_forward(af, pf, ray_batch, z_all, R, N, raw_f, training ? ws + L.act_f : nullptr, stream)) < 0) return rc;
+        if ((rc = nk_raw2outputs(raw_f, z_all, ray_batch, R, N, o, NK_STREAM_NOISE_FINE, out->rgb_fine, out->disp_fine,
+                                 out->acc_fine, out->depth_fine, nullptr, stream)) < 0) return rc;
+    }
+    return NK_OK;
+}
+
+extern "C" int nk_render_rays_bwd(const nk_arch* ac, const void* pc, const nk_arch* af, const void* pf,
+                                  const float* ray_batch, int64_t R, const nk_render_opts* o, void* workspace,
+                                  int64_t workspace_bytes, const float* d_rgb_fine, const float* d_rgb_coarse,
+                                  float* grad_coarse, float* grad_fine, void* stream) {
+    if (!ac || !pc || !ray_batch || !o || !workspace) NK_FAIL(NK_ERR_ARG, "nk_render_rays_bwd: null pointer");
+    WsLayout L;
+    int rc = layout(ac, af, o, R, 1, &L);
+    if (rc < 0) return rc;
+    if (workspace_bytes < L.total)
+        NK_FAIL(NK_ERR_WORKSPACE, "nk_render_rays_bwd: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)L.total);
+    const int Nc = o->num_coarse, Nf = o->num_fine, N = Nc + Nf;
+    char* ws = (char*)workspace;
+    float* d_raw = (float*)(ws + L.d_raw);
+    if (Nf > 0 && d_rgb_fine) {
+        if (!pf || !grad_fine) NK_FAIL(NK_ERR_ARG, "nk_render_rays_bwd: fine gradient requested without packed_fine / grad_fine");
+        if ((rc = nk_raw2outputs_bwd((float*)(ws + L.raw_f), (float*)(ws + L.z_all), ray_batch, R, N, o,
+                                     NK_STREAM_NOISE_FINE, d_rgb_fine, nullptr, nullptr, d_raw, stream)) < 0) return rc;
+        if ((rc = nk_mlp_backward(af, pf, ws + L.act_f, d_raw, R, N, ws + L.dz, grad_fine, stream)) < 0) return rc;
+    }
+    if (d_rgb_coarse) {
+        if (!grad_coarse) NK_FAIL(NK_ERR_ARG, "nk_render_rays_bwd: coarse gradient requested without grad_coarse");
+        if ((rc = nk_raw2outputs_bwd((float*)(ws + L.raw_c), (float*)(ws + L.z_c), ray_batch, R, Nc, o,
+                                     NK_STREAM_NOISE_COARSE, d_rgb_coarse, nullptr, nullptr, d_raw, stream)) < 0) return rc;
+        if ((rc = nk_mlp_backward(ac, pc, ws + L.act_c, d_raw, R, Nc, ws + L.dz, grad_coarse, stream)) < 0) return rc;
+    }
+    return NK_OK;
+}

@@ -1,0 +1,141 @@
+// Shared declarations of the gfx950 NeRF render path: error reporting, the counter-based RNG,
+// MFMA operand types and the network plan (how an nk_arch maps onto fragment streams).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nerf_kinematics.h"
+
+#define NK_HD __host__ __device__ __forceinline__
+#define NK_D __device__ __forceinline__
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define NK_LDS __attribute__((address_space(3)))
+#define NK_GLB __attribute__((address_space(1)))
+
+// ---- error reporting (host) ---------------------------------------------------------------
+void nk_set_error(const char* fmt, ...);
+#define NK_FAIL(code, ...) do { nk_set_error(__VA_ARGS__); return (code); } while (0)
+#define NK_CHECK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    nk_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return NK_ERR_HIP; } } while (0)
+#define NK_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    nk_set_error("launch of %s failed: %s", name, hipGetErrorString(e_)); return NK_ERR_HIP; } } while (0)
+
+// ---- counter-based RNG: 32 bits for element idx of a stream under a seed --------------------
+enum { NK_STREAM_STRATIFIED = 0, NK_STREAM_PDF = 1, NK_STREAM_NOISE_COARSE = 2,
+       NK_STREAM_NOISE_FINE = 3, NK_STREAM_PIXELS = 4 };
+
+NK_HD uint32_t nk_lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+NK_HD uint32_t nk_rand_u32(uint32_t seed, uint32_t stream, uint64_t idx) {
+    const uint32_t key = nk_lowbias32(seed ^ (stream * 0x85EBCA6Bu));
+    const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t x = lo * 0x9E3779B9u + key;
+    return nk_lowbias32(x ^ (hi * 0xC2B2AE35u));
+}
+NK_HD float nk_rand_uniform(uint32_t seed, uint32_t stream, uint64_t idx) {
+    return (float)(nk_rand_u32(seed, stream, idx) >> 8) * (1.0f / 16777216.0f);
+}
+NK_D float nk_rand_normal(uint32_t seed, uint32_t stream, uint64_t idx) {
+    const uint32_t a = nk_rand_u32(seed, stream, 2 * idx), b = nk_rand_u32(seed, stream, 2 * idx + 1);
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+// torch.linspace(0, 1, steps)[i] in float32: forward from 0 for the first half, backward from 1
+// for the second (the symmetric form torch uses), so coarse depths match the reference bitwise.
+NK_HD float nk_linspace01(int i, int steps) {
+    if (steps <= 1) return 0.0f;
+    const float step = 1.0f / (float)(steps - 1);
+    return (i < steps / 2) ? step * (float)i : 1.0f - step * (float)(steps - 1 - i);
+}
+
+// ---- positional-encoding slot maps --------------------------------------------------------
+// The MLP kernels hold gamma(x) as 64 k-slots and gamma(d) as 32 k-slots of MFMA B operands.
+// Slot sigma = 16*s + 8*h + j is element j of lane-half h in k-step s.  These give the column of
+// the reference encoding [x, sin(2^0 x), cos(2^0 x), ...] a slot carries, or -1 for padding.
+NK_HD int nk_pe_xyz_col(int q /* 8*s + j */, int h, int L) {
+    if (q < 30) { const int l = 5 * h + q / 6; return l < L ? 3 + 6 * l + q % 6 : -1; }
+    if (q == 30) return h == 0 ? 0 : 2;
+    return h == 0 ? 1 : -1;
+}
+NK_HD int nk_pe_dir_col(int q /* 8*s + j */, int h, int L) {
+    if (q < 12) { const int l = 2 * h + q / 6; return l < L ? 3 + 6 * l + q % 6 : -1; }
+    if (q == 12) return h == 0 ? 0 : 2;
+    if (q == 13) return h == 0 ? 1 : -1;
+    return -1;
+}
+
+// ---- network plan ---------------------------------------------------------------------------
+// Layers in forward order: trunk 0..D-1, then ALPHA, FEAT, VIEWS, RGB.
+enum { NK_SEG_ACT = 0, NK_SEG_PEX = 1, NK_SEG_PED = 2, NK_SEG_DOUT = 3 };
+enum { NK_MAX_LAYERS = 12 };
+
+struct NkLayer {
+    int w_off, b_off;       // offsets of weight / bias in the flat fp32 parameter array
+    int out_dim, in_dim;    // shape of the reference weight matrix [out_dim, in_dim]
+    int n_tiles;            // 32-row output tiles
+    int n_seg;              // forward K segments, in k-step order
+    int seg_type[3], seg_steps[3], seg_col[3];
+    int nk;                 // forward k-steps (16 input features each)
+    int fwd_block0;         // first 1-KiB block of this layer in the forward stream;
+                            // each tile takes nk weight blocks + 1 bias block
+    // transposed stream (dH_in = W^T dZ): rows = the ACT input features of this layer
+    int bwd_tiles;          // 32-row tiles of the ACT input (0: layer has no transposed pass)
+    int bwd_nk;             // k-steps over the output features (+1 dOut step for FEAT)
+    int bwd_act_col;        // first column of the ACT input inside the reference matrix
+    int bwd_block0;         // first block in the transposed stream
+};
+
+struct NkPlan {
+    int D, W, WD, skip, Lx, Ld, relu_first, relu_feat, lineage;
+    int NL;                 // D + 4
+    NkLayer layer[NK_MAX_LAYERS];
+    int fwd_blocks, bwd_blocks;   // stream lengths in 1-KiB blocks
+    int n_params;
+};
+
+// Activation regions saved by the forward pass, each [G][width/8][32][8] bf16.
+// index: 0 = gamma(x) slots (64), 1 = gamma(d) slots (32), 2+i = h_i (W), 2+D = feat (W), 3+D = g (WD)
+NK_HD int nk_act_width(const NkPlan& p, int idx) {
+    if (idx == 0) return 64;
+    if (idx == 1) return 32;
+    if (idx < 2 + p.D + 1) return p.W;
+    return p.WD;
+}
+NK_HD int64_t nk_act_offset(const NkPlan& p, int idx, int64_t G) {   // bytes
+    int64_t feats = 0;
+    for (int i = 0; i < idx; ++i) feats += nk_act_width(p, i);
+    return feats * G * 64;      // 32 points * 2 bytes
+}
+NK_HD int nk_act_count(const NkPlan& p) { return p.D + 4; }
+
+// dZ regions written by the backward chain: 0 = dOut (32: dr,dg,db,dsigma), 1 = dZ_views (WD),
+// 2 = dZ_feat (W), 3+i = dZ of trunk layer D-1-i (W)
+NK_HD int nk_dz_width(const NkPlan& p, int idx) {
+    if (idx == 0) return 32;
+    if (idx == 1) return p.WD;
+    return p.W;
+}
+NK_HD int64_t nk_dz_offset(const NkPlan& p, int idx, int64_t G) {
+    int64_t feats = 0;
+    for (int i = 0; i < idx; ++i) feats += nk_dz_width(p, i);
+    return feats * G * 64;
+}
+NK_HD int nk_dz_count(const NkPlan& p) { return p.D + 3; }
+
+// groups of 32 points, padded to whole 256-point workgroups
+static inline int64_t nk_groups(int64_t P) { return ((P + 255) / 256) * 8; }
+
+int nk_build_plan(const nk_arch* arch, NkPlan* plan);   // host; returns nk_status
+
+static inline hipStream_t nk_stream(void* s) { return (hipStream_t)s; }

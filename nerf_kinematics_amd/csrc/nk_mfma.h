@@ -1,0 +1,128 @@
+// Device helpers shared by the MLP kernels: MFMA operand fragments, bf16 packing, the
+// positional-encoding fragments, the LDS weight stream and the activation tile store.
+#pragma once
+#include "nk_common.h"
+
+union Frag { u32x4 u; bf16x8 b; };
+
+NK_D uint32_t pack_bf16(float lo, float hi) {
+    bf16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// sin / cos of x * 2^l with a two-constant reduction to one revolution, then v_sin / v_cos
+// (which take revolutions).  Absolute error ~1e-6, far below the bf16 operand rounding.
+NK_D void sincos_rev(float x, float& s, float& c) {
+    const float C_HI = 0.15915494f, C_LO = 3.0994494e-9f;      // 1/(2 pi) split
+    const float n = rintf(x * C_HI);
+    float r = fmaf(x, C_HI, -n);
+    r = fmaf(x, C_LO, r);
+    s = __builtin_amdgcn_sinf(r);
+    c = __builtin_amdgcn_cosf(r);
+}
+
+// gamma(x) as 4 B-operand fragments (k-slots per nk_pe_xyz_col)
+NK_D void pe_xyz_frags(float px, float py, float pz, int h, Frag (&f)[4]) {
+    float v[32];
+    const float base = h ? 32.0f : 1.0f;
+#pragma unroll
+    for (int fi = 0; fi < 5; ++fi) {
+        const float sc = base * (float)(1 << fi);
+        sincos_rev(px * sc, v[6 * fi + 0], v[6 * fi + 3]);
+        sincos_rev(py * sc, v[6 * fi + 1], v[6 * fi + 4]);
+        sincos_rev(pz * sc, v[6 * fi + 2], v[6 * fi + 5]);
+    }
+    v[30] = h ? pz : px;
+    v[31] = h ? 0.0f : py;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) f[s].u[w] = pack_bf16(v[8 * s + 2 * w], v[8 * s + 2 * w + 1]);
+}
+
+// gamma(d) as 2 fragments (k-slots per nk_pe_dir_col)
+NK_D void pe_dir_frags(float dx, float dy, float dz, int h, Frag (&f)[2]) {
+    float v[16];
+    const float base = h ? 4.0f : 1.0f;
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi) {
+        const float sc = base * (float)(1 << fi);
+        sincos_rev(dx * sc, v[6 * fi + 0], v[6 * fi + 3]);
+        sincos_rev(dy * sc, v[6 * fi + 1], v[6 * fi + 4]);
+        sincos_rev(dz * sc, v[6 * fi + 2], v[6 * fi + 5]);
+    }
+    v[12] = h ? dz : dx;
+    v[13] = h ? 0.0f : dy;
+    v[14] = 0.0f; v[15] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) f[s].u[w] = pack_bf16(v[8 * s + 2 * w], v[8 * s + 2 * w + 1]);
+}
+
+// The weight stream: stage i sits in ring half (i & 1); a stage is loaded while the previous one
+// is consumed.  All 8 waves issue the loads (block b by wave b % 8) and all pass one barrier per
+// stage, which both publishes the landed stage and retires the reads of the one being replaced.
+struct WStream {
+    const char* g;      // next byte of the stream to load
+    char* ring;         // LDS base
+    int half_bytes;
+    int cur;            // ring half holding the stage being consumed
+    int wave, lane;
+    NK_D void issue(int nb) {        // load the next stage (nb blocks) into the other half
+        char* dst = ring + (cur ^ 1) * half_bytes;
+        for (int b = wave; b < nb; b += 8)
+            __builtin_amdgcn_global_load_lds((const NK_GLB void*)(g + (int64_t)b * 1024 + lane * 16),
+                                             (NK_LDS void*)(dst + b * 1024), 16, 0, 0);
+        g += (int64_t)nb * 1024;
+    }
+    NK_D void flip() {               // end of stage: loaded data visible, old half free
+        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
+        __syncthreads();
+        cur ^= 1;
+    }
+    NK_D const char* stage() const { return ring + cur * half_bytes; }
+};
+
+// bias fragment of a stage (block index nk): 16 floats for this lane-half
+NK_D f32x16 lds_bias(const char* stage, int nk, int h) {
+    const f32x4* b = (const f32x4*)(stage + nk * 1024 + h * 64);
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t = b[q];
+        v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+    return v;
+}
+
+template <int NK>
+NK_D f32x16 tile_mfma(f32x16 acc, const char* stage, int blk0, const Frag* bf, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const bf16x8 a = *(const bf16x8*)(stage + (blk0 + ks) * 1024 + lane * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[ks].b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// store one bf16 activation tile: octets 4t..4t+3 of region `dst` ([G][NO][32][8] bf16)
+NK_D void save_tile(char* dst, int64_t grp, int NO, int t, int c, int h, const Frag& f0, const Frag& f1) {
+    // features 8q+4h+{0..3} of tile t are dwords (2q&3.., ) of fragment q>>1
+    char* base = dst + ((grp * NO + 4 * t) * 32 + c) * 16 + 8 * h;
+    *(u32x2*)(base + 0 * 512) = u32x2{f0.u[0], f0.u[1]};
+    *(u32x2*)(base + 1 * 512) = u32x2{f0.u[2], f0.u[3]};
+    *(u32x2*)(base + 2 * 512) = u32x2{f1.u[0], f1.u[1]};
+    *(u32x2*)(base + 3 * 512) = u32x2{f1.u[2], f1.u[3]};
+}
+
+NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        float x0 = a[2 * w], x1 = a[2 * w + 1], y0 = a[8 + 2 * w], y1 = a[8 + 2 * w + 1];
+        if (relu) { x0 = fmaxf(x0, 0.0f); x1 = fmaxf(x1, 0.0f); y0 = fmaxf(y0, 0.0f); y1 = fmaxf(y1, 0.0f); }
+        f0.u[w] = pack_bf16(x0, x1);
+        f1.u[w] = pack_bf16(y0, y1);
+    }
+}
+

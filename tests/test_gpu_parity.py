@@ -1,0 +1,270 @@
+"""GPU parity tests: every stage of the HIP render path, called through the C ABI, against the
+CPU oracle on the same seeded inputs, and against the committed golden vectors.
+
+Tolerances (stated per test):
+  fp32 stages (rays, depths, compositing, sampling, Adam)   rtol 1e-5 .. 2e-4
+  bf16 MFMA MLP vs an oracle that rounds at the same places  raw: 2e-2 of the row scale
+  bf16 MLP vs the fp32 oracle, image level                   |rgb| <= 0.06, PSNR within 0.1 dB
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nk():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU and the HIP library; there is no CPU fallback")
+    import nerf_kinematics_amd as nk
+    nk.load()
+    return nk
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def lego_w(golden_dir):
+    return np.load(os.path.join(golden_dir, "lego_lowres3_weights.npz"))
+
+
+def probe_rays(H, W):
+    focal = 0.5 * W / math.tan(0.5 * 0.6911112070083618)
+    c2w = O.spherical_pose(45.0, -30.0, 4.0)
+    ro, rd = O.get_rays(H, W, focal, c2w)
+    return O.make_ray_batch(ro, rd, 2.0, 6.0), c2w, focal
+
+
+def oarch(a):
+    return O.Arch(a.depth, a.width, a.skip, a.dir_width, a.n_freq_xyz, a.n_freq_dir, a.relu_first, a.relu_feat, a.lineage)
+
+
+# ---------------------------------------------------------------------------------------------
+# rays and depths (fp32, rtol 1e-5)
+# ---------------------------------------------------------------------------------------------
+def test_get_rays_matches_oracle(nk, dev):
+    H, W = 37, 53
+    rb_ref, c2w, focal = probe_rays(H, W)
+    rb = nk.get_rays(H, W, focal, c2w, near=2.0, far=6.0, device=dev)
+    np.testing.assert_allclose(rb.cpu().numpy(), rb_ref.numpy(), rtol=1e-5, atol=1e-6)
+    # selected pixels
+    pix = torch.tensor([0, 5, H * W - 1, 1000], dtype=torch.int32, device=dev)
+    rb2 = nk.get_rays(H, W, focal, c2w, near=2.0, far=6.0, pixels=pix)
+    np.testing.assert_allclose(rb2.cpu().numpy(), rb_ref[pix.cpu().long()].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_ndc_rays_matches_oracle(nk, dev):
+    H, W, focal = 24, 40, 30.0
+    c2w = torch.tensor([[1, 0, 0, 0.1], [0, 1, 0, -0.2], [0, 0, 1, 0.3]], dtype=torch.float32)
+    ro, rd = O.get_rays(H, W, focal, c2w)
+    vd = rd / rd.norm(dim=-1, keepdim=True)
+    ro2, rd2 = O.ndc_rays(H, W, focal, 1.0, ro, rd)
+    ref = torch.cat([ro2.reshape(-1, 3), rd2.reshape(-1, 3), torch.zeros(H * W, 1), torch.ones(H * W, 1),
+                     vd.reshape(-1, 3)], -1)
+    rb = nk.get_rays(H, W, focal, c2w, near=0.0, far=1.0, ndc=True, device=dev)
+    np.testing.assert_allclose(rb.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("perturb,lindisp", [(False, False), (True, False), (False, True), (True, True)])
+def test_stratified_z(nk, dev, perturb, lindisp):
+    rb, _, _ = probe_rays(16, 16)
+    opts = nk.make_opts(64, 128, perturb=perturb, lindisp=lindisp, seed=1234)
+    z = nk.stratified_z(rb.to(dev), opts).cpu()
+    u = None
+    if perturb:
+        u = torch.from_numpy(O.rand_uniform(1234, O.STREAM_STRATIFIED, np.arange(256 * 64, dtype=np.uint64))).view(256, 64)
+    ref = O.stratified_z(rb, 64, lindisp, u)
+    np.testing.assert_allclose(z.numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
+    assert torch.all(z[:, 1:] >= z[:, :-1])
+
+
+# ---------------------------------------------------------------------------------------------
+# compositing (fp32): forward rtol 2e-5, backward vs autograd rtol 2e-4
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [32, 64, 128, 192, 200])
+@pytest.mark.parametrize("white,noise", [(False, 0.0), (True, 0.0), (False, 0.2)])
+def test_raw2outputs_forward_backward(nk, dev, n, white, noise):
+    torch.manual_seed(n)
+    R = 37
+    rb, _, _ = probe_rays(8, 8)
+    rb = rb[:R].contiguous()
+    z = torch.sort(torch.rand(R, n) * 4 + 2, -1)[0]
+    raw = torch.randn(R, n, 4) * 2
+    raw[0, :, 3] = -5.0            # empty ray
+    raw[1, n // 2, 3] = 1e4        # opaque wall in the middle
+    seed = 77
+    opts = nk.make_opts(64, 128, radiance_field_noise_std=noise, white_background=white, seed=seed)
+    nz = None
+    if noise > 0:
+        nz = torch.from_numpy(O.rand_normal(seed, O.STREAM_NOISE_FINE, np.arange(R * n, dtype=np.uint64))).view(R, n) * noise
+    raw_ref = raw.clone().requires_grad_(True)
+    rgb, disp, acc, w, depth = O.raw2outputs(raw_ref, z, rb[:, 3:6], nz, white)
+    out = nk.raw2outputs(raw.to(dev), z.to(dev), rb.to(dev), opts, O.STREAM_NOISE_FINE)
+    tol = dict(rtol=3e-5, atol=3e-6) if noise == 0 else dict(rtol=2e-3, atol=2e-4)   # device vs numpy log/cos ulps
+    np.testing.assert_allclose(out["rgb"].cpu().numpy(), rgb.detach().numpy(), **tol)
+    np.testing.assert_allclose(out["acc"].cpu().numpy(), acc.detach().numpy(), **tol)
+    np.testing.assert_allclose(out["depth"].cpu().numpy(), depth.detach().numpy(), **tol)
+    np.testing.assert_allclose(out["weights"].cpu().numpy(), w.detach().numpy(), **tol)
+    np.testing.assert_allclose(out["disp"].cpu().numpy(), disp.detach().numpy(), rtol=1e-3, atol=1e-5, equal_nan=True)
+    # backward
+    g = torch.randn(R, 3)
+    (rgb * g).sum().backward()
+    d_raw = nk.raw2outputs_backward(raw.to(dev), z.to(dev), rb.to(dev), opts, O.STREAM_NOISE_FINE, g.to(dev)).cpu()
+    ref = raw_ref.grad
+    scale = ref.abs().max().item()
+    btol = 2e-4 if noise == 0 else 5e-3
+    assert float((d_raw - ref).abs().max()) <= btol * scale + 1e-7, (float((d_raw - ref).abs().max()), scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# hierarchical sampling (fp32, atol 2e-5 on depths in [2, 6])
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Nc,Nf", [(64, 128), (64, 64), (32, 32), (16, 40)])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_sample_pdf(nk, dev, Nc, Nf, perturb):
+    torch.manual_seed(Nc + Nf)
+    R = 50
+    z = torch.sort(torch.rand(R, Nc) * 4 + 2, -1)[0]
+    w = torch.rand(R, Nc) ** 4
+    w[0] = 0.0                       # empty ray: uniform pdf
+    w[1] = 0.0; w[1, Nc // 2] = 1.0  # one spike
+    seed = 99
+    opts = nk.make_opts(Nc, Nf, perturb=perturb, seed=seed)
+    z_all, z_s = nk.sample_pdf(z.to(dev), w.to(dev), opts)
+    u = None
+    if perturb:
+        u = torch.from_numpy(O.rand_uniform(seed, O.STREAM_PDF, np.arange(R * Nf, dtype=np.uint64))).view(R, Nf)
+    mids = 0.5 * (z[:, 1:] + z[:, :-1])
+    ref_s = O.sample_pdf(mids, w[:, 1:-1], Nf, det=not perturb, u=u)
+    ref_all = torch.sort(torch.cat([z, ref_s], -1), -1)[0]
+    np.testing.assert_allclose(z_s.cpu().numpy(), ref_s.numpy(), rtol=0, atol=3e-5)
+    np.testing.assert_allclose(z_all.cpu().numpy(), ref_all.numpy(), rtol=0, atol=3e-5)
+    assert torch.all(z_all[:, 1:] >= z_all[:, :-1])      # sortedness, size independent
+
+
+# ---------------------------------------------------------------------------------------------
+# MLP forward (bf16 MFMA)
+# ---------------------------------------------------------------------------------------------
+def _mlp_compare(nk, dev, arch, flat, R, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    rb, _, _ = probe_rays(16, 16)
+    rb = rb[torch.randperm(256, generator=g)[:R]].contiguous()
+    z = torch.sort(torch.rand(R, n, generator=g) * 4 + 2, -1)[0]
+    model = nk.NeRFModel(arch, flat.to(dev))
+    raw = nk.run_network(model, rb.to(dev), z.to(dev)).cpu()
+    emu = O.NeRFNet.from_flat(oarch(arch), flat, emulate_bf16=True)
+    with torch.no_grad():
+        ref = O._run_net(emu, rb, z)
+    return raw, ref
+
+
+def test_mlp_forward_lego_checkpoint(nk, dev, lego_w):
+    """Trained 4x128 FlexibleNeRFModel weights; oracle rounds to bf16 where the kernel does.
+    Tolerance: 2e-2 of the per-output scale (outputs reach |3000|; accumulation order differs)."""
+    raw, ref = _mlp_compare(nk, dev, nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["fine"]), 40, 64, 0)
+    err = (raw - ref).abs()
+    scale = ref.abs().reshape(-1, 4).max(0)[0]
+    assert torch.all(err.reshape(-1, 4).max(0)[0] <= 2e-2 * scale + 1e-2), (err.reshape(-1, 4).max(0)[0], scale)
+    assert float(err.mean()) < 2e-3 * float(scale.mean())
+
+
+def test_mlp_forward_ragged_point_count(nk, dev, lego_w):
+    """P = R*n not a multiple of 256 or 32 (padding lanes must not leak)."""
+    raw, ref = _mlp_compare(nk, dev, nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["coarse"]), 7, 33, 1)
+    scale = ref.abs().max()
+    assert float((raw - ref).abs().max()) <= 2e-2 * float(scale) + 1e-2
+
+
+def test_mlp_forward_wheel_checkpoint(nk, dev, golden_dir):
+    """L=6 encoding (39 inputs): the unused frequency slots must be dead."""
+    w = np.load(os.path.join(golden_dir, "wheel_robot6_weights.npz"))
+    raw, ref = _mlp_compare(nk, dev, nk.ARCH_WHEEL_CKPT, torch.from_numpy(w["fine"]), 16, 64, 2)
+    scale = ref.abs().reshape(-1, 4).max(0)[0]
+    assert torch.all((raw - ref).abs().reshape(-1, 4).max(0)[0] <= 2e-2 * scale + 1e-2)
+
+
+def test_mlp_forward_run_nerf_8x256(nk, dev):
+    """The 8x256 skip network of run_nerf.py, torch.nn.Linear default init (seed 42)."""
+    flat = O.NeRFNet.init_flat(O.ARCH_RUN_NERF, 42)
+    raw, ref = _mlp_compare(nk, dev, nk.ARCH_RUN_NERF, flat, 16, 192, 3)
+    assert float((raw - ref).abs().max()) <= 5e-3, float((raw - ref).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+# render_rays end to end
+# ---------------------------------------------------------------------------------------------
+def test_render_rays_golden_vectors(nk, dev, lego_w, golden_dir):
+    """Committed oracle vectors (fp32 reference) vs the bf16 HIP path, deterministic and perturbed."""
+    g = np.load(os.path.join(golden_dir, "lego_stage_vectors.npz"))
+    rb = torch.from_numpy(g["ray_batch"]).to(dev)
+    c = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["coarse"]).to(dev))
+    f = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["fine"]).to(dev))
+    for tag, kw in (("det", {}), ("rnd", dict(perturb=True, radiance_field_noise_std=0.2, seed=42))):
+        with torch.no_grad():
+            rgb_f, disp_f, acc_f, rgb_c, disp_c, acc_c = nk.render_rays(rb, c, f, num_coarse=64, num_fine=128, **kw)
+        assert float((rgb_f.cpu() - torch.from_numpy(g[f"{tag}_rgb_fine"])).abs().max()) < 0.06, tag
+        assert float((rgb_c.cpu() - torch.from_numpy(g[f"{tag}_rgb_coarse"])).abs().max()) < 0.06, tag
+        assert float((acc_f.cpu() - torch.from_numpy(g[f"{tag}_acc_fine"])).abs().max()) < 0.1, tag
+
+
+def test_render_image_psnr_within_0p1_db(nk, dev, lego_w):
+    """100x100 probe view: bf16 HIP render vs fp32 oracle render; both scored against the same
+    held-out target (the oracle's own fp64-free render is the 'ground truth' teacher here)."""
+    H = W = 64
+    rb, c2w, focal = probe_rays(H, W)
+    co = O.NeRFNet.from_flat(O.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["coarse"]))
+    fo = O.NeRFNet.from_flat(O.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["fine"]))
+    with torch.no_grad():
+        ref = O.render_rays(rb, co, fo, O.RenderOpts(64, 128))
+    c = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["coarse"]).to(dev))
+    f = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["fine"]).to(dev))
+    rbg = nk.get_rays(H, W, focal, c2w, near=2.0, far=6.0, device=dev)
+    with torch.no_grad():
+        rgb = nk.render_rays(rbg, c, f, num_coarse=64, num_fine=128)[0].cpu()
+    d = rgb - ref["rgb_fine"]
+    assert float(d.abs().max()) < 0.06
+    assert -10 * math.log10(float((d ** 2).mean())) > 45.0          # images agree to > 45 dB
+    # score both against a noisy "photograph" of the scene: PSNR must agree within 0.1 dB
+    gen = torch.Generator().manual_seed(0)
+    photo = (ref["rgb_fine"] + 0.05 * torch.randn(H * W, 3, generator=gen)).clamp(0, 1)
+    psnr = lambda x: -10 * math.log10(float(((x - photo) ** 2).mean()))
+    assert abs(psnr(rgb) - psnr(ref["rgb_fine"])) < 0.1
+    # centre opaque, corners empty (the checkpoint pin, on the GPU path)
+    acc = nk.render_rays(rbg, c, f, num_coarse=64, num_fine=128)[2].view(H, W).cpu()
+    assert acc[24:40, 24:40].mean() > 0.999 and acc[:6, :6].mean() < 1e-3
+
+
+def test_render_coarse_only_config1(nk, dev, lego_w):
+    """BASELINE config 1 shape: 32 coarse samples, no fine pass."""
+    rb, _, _ = probe_rays(20, 20)
+    co = O.NeRFNet.from_flat(O.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["coarse"]))
+    with torch.no_grad():
+        ref = O.render_rays(rb, co, None, O.RenderOpts(32, 0))
+    c = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["coarse"]).to(dev))
+    with torch.no_grad():
+        out = nk.render_rays(rb.to(dev), c, None, num_coarse=32, num_fine=0)
+    assert float((out[3].cpu() - ref["rgb_coarse"]).abs().max()) < 0.06
+    assert torch.equal(out[0], out[3])
+
+
+def test_bad_arguments_raise(nk, dev, lego_w):
+    c = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["coarse"]).to(dev))
+    with pytest.raises(ValueError):
+        nk.render_rays(torch.zeros(4, 8, device=dev), c, None, num_coarse=32, num_fine=0)
+    with pytest.raises(ValueError):
+        nk.render_rays(torch.zeros(4, 11, device=dev, dtype=torch.float64), c, None, num_coarse=32, num_fine=0)
+    with pytest.raises(ValueError):
+        nk.render_rays(torch.zeros(4, 11, device=dev), c, None, num_coarse=64, num_fine=128)
+    with pytest.raises(ValueError):
+        nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.zeros(10, device=dev))
+    with pytest.raises(Exception):
+        nk.NeRFModel(nk.Arch(depth=8, width=192, skip=4, dir_width=96), torch.zeros(10, device=dev))

@@ -1,0 +1,148 @@
+"""CPU tests of the oracle itself: it must reproduce the committed golden vectors and the
+behavioural pin on the reference's lego checkpoint (the only thing in the reference that
+constrains the render path, since its source is an un-vendored submodule)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+
+@pytest.fixture(scope="module")
+def lego(golden_dir):
+    w = np.load(os.path.join(golden_dir, "lego_lowres3_weights.npz"))
+    c = O.NeRFNet.from_flat(O.ARCH_LEGO_CKPT, torch.from_numpy(w["coarse"]))
+    f = O.NeRFNet.from_flat(O.ARCH_LEGO_CKPT, torch.from_numpy(w["fine"]))
+    return w, c, f
+
+
+def test_checkpoint_structure(golden_dir, lego):
+    w, _, _ = lego
+    assert w["coarse"].shape == (84548,) and w["fine"].shape == (84548,)
+    assert O.ARCH_LEGO_CKPT.num_params() == 84548
+    ww = np.load(os.path.join(golden_dir, "wheel_robot6_weights.npz"))
+    assert ww["coarse"].shape == (81476,) == (O.ARCH_WHEEL_CKPT.num_params(),)
+    assert O.ARCH_RUN_NERF.num_params() == 595844
+    # stored scalars: psnr == -10 log10(loss); lr follows the exponential schedule
+    assert abs(float(w["psnr"]) + 10 * math.log10(float(w["loss"]))) < 2e-2
+    assert abs(O.lr_at(int(w["iter"]), 0.005) - float(w["lr"])) < 1e-12
+    assert abs(O.lr_at(int(ww["iter"]), 0.001) - float(ww["lr"])) < 1e-12
+
+
+def test_probe_render_is_coherent(golden_dir, lego):
+    """Only the right conventions give an opaque centre, empty corners and the bulldozer's colour."""
+    _, c, f = lego
+    H = W = 50
+    focal = 0.5 * W / math.tan(0.5 * 0.6911112070083618)
+    ro, rd = O.get_rays(H, W, focal, O.spherical_pose(45.0, -30.0, 4.0))
+    rb = O.make_ray_batch(ro, rd, 2.0, 6.0)
+    with torch.no_grad():
+        out = O.render_rays(rb, c, f, O.RenderOpts(64, 128))
+    rgb = out["rgb_fine"].view(H, W, 3).numpy()
+    acc = out["acc_fine"].view(H, W).numpy()
+    stats = json.load(open(os.path.join(golden_dir, "lego_probe_stats.json")))
+    assert acc[20:30, 20:30].mean() > 0.999
+    assert acc[:5, :5].mean() < 1e-3
+    assert np.allclose(rgb.reshape(-1, 3).mean(0), stats["mean_rgb"], atol=0.01)
+    assert np.allclose(stats["mean_rgb"], [0.18, 0.15, 0.10], atol=0.01)
+
+
+def test_wrong_conventions_fail_the_pin(lego):
+    """ReLU after layer1 or no ReLU on fc_feat visibly break the render (the discriminating pin)."""
+    w, _, _ = lego
+    H = W = 24
+    focal = 0.5 * W / math.tan(0.5 * 0.6911112070083618)
+    ro, rd = O.get_rays(H, W, focal, O.spherical_pose(45.0, -30.0, 4.0))
+    rb = O.make_ray_batch(ro, rd, 2.0, 6.0)
+    import dataclasses
+    bad = dataclasses.replace(O.ARCH_LEGO_CKPT, relu_feat=False)
+    c = O.NeRFNet.from_flat(bad, torch.from_numpy(w["coarse"]))
+    f = O.NeRFNet.from_flat(bad, torch.from_numpy(w["fine"]))
+    with torch.no_grad():
+        rgb = O.render_rays(rb, c, f, O.RenderOpts(64, 128))["rgb_fine"].mean(0).numpy()
+    assert rgb[0] > 0.25 and rgb[1] < 0.05 and rgb[2] < 0.05     # pure red
+
+
+@pytest.mark.parametrize("tag,opts", [("det", O.RenderOpts(64, 128)),
+                                       ("rnd", O.RenderOpts(64, 128, perturb=True, radiance_field_noise_std=0.2, seed=42))])
+def test_golden_stage_vectors(golden_dir, lego, tag, opts):
+    _, c, f = lego
+    g = np.load(os.path.join(golden_dir, "lego_stage_vectors.npz"))
+    rb = torch.from_numpy(g["ray_batch"])
+    with torch.no_grad():
+        out = O.render_rays(rb, c, f, opts)
+    for k, v in out.items():
+        np.testing.assert_allclose(v.numpy(), g[f"{tag}_{k}"], rtol=2e-4, atol=2e-5, equal_nan=True, err_msg=k)
+
+
+def test_rng_streams_are_stable():
+    idx = np.arange(5, dtype=np.uint64)
+    assert O.rand_u32(42, 0, idx).tolist() == O.rand_u32(42, 0, idx).tolist()
+    u = O.rand_uniform(7, 1, np.arange(100000, dtype=np.uint64))
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 5e-3
+    n = O.rand_normal(7, 2, np.arange(100000, dtype=np.uint64))
+    assert abs(n.mean()) < 1e-2 and abs(n.std() - 1.0) < 1e-2
+    # 64-bit indices reach the high word
+    assert O.rand_u32(1, 0, np.array([1 << 32], dtype=np.uint64))[0] != O.rand_u32(1, 0, np.array([0], dtype=np.uint64))[0]
+
+
+def test_sample_pdf_edge_cases():
+    bins = torch.linspace(2, 6, 63)[None]
+    # all-zero weights -> uniform pdf -> samples spread evenly over the bins
+    z = O.sample_pdf(bins, torch.zeros(1, 62), 128)
+    assert torch.all(z[:, 1:] >= z[:, :-1]) and abs(float(z[0, 0]) - 2) < 1e-5 and abs(float(z[0, -1]) - 6) < 1e-4
+    # a single spike -> every sample lands in that bin
+    w = torch.zeros(1, 62); w[0, 30] = 1.0
+    z = O.sample_pdf(bins, w, 128)
+    inside = ((z >= bins[0, 30] - 1e-4) & (z <= bins[0, 31] + 1e-4)).float().mean()
+    assert inside > 0.97
+
+
+def test_raw2outputs_properties():
+    torch.manual_seed(0)
+    raw = torch.randn(8, 64, 4)
+    z = torch.linspace(2, 6, 64).expand(8, 64)
+    d = torch.randn(8, 3)
+    rgb, disp, acc, w, depth = O.raw2outputs(raw, z, d)
+    assert torch.all(w >= 0) and torch.all(acc <= 1 + 1e-5)
+    # opaque far sample: weights sum to one when the last sigma is positive
+    raw[..., -1, 3] = 1.0
+    _, _, acc, _, _ = O.raw2outputs(raw, z, d)
+    assert torch.allclose(acc, torch.ones(8), atol=1e-5)
+    # empty ray: zero density everywhere -> acc 0, disp NaN (0/0) as in the reference formula
+    raw[..., 3] = -1.0
+    rgb, disp, acc, _, _ = O.raw2outputs(raw, z, d)
+    assert torch.all(acc == 0) and torch.all(torch.isnan(disp)) and torch.all(rgb == 0)
+    rgbw, *_ = O.raw2outputs(raw, z, d, white_background=True)
+    assert torch.allclose(rgbw, torch.ones(8, 3))
+
+
+def test_bf16_emulation_is_close_to_fp32(lego):
+    w, c, f = lego
+    g = torch.Generator().manual_seed(0)
+    x = O.positional_encoding(torch.rand(256, 3, generator=g) * 2 - 1, 10)
+    d = O.positional_encoding(torch.nn.functional.normalize(torch.randn(256, 3, generator=g), dim=-1), 4)
+    emu = O.NeRFNet.from_flat(O.ARCH_LEGO_CKPT, torch.from_numpy(w["fine"]), emulate_bf16=True)
+    with torch.no_grad():
+        a, b = f(x, d), emu(x, d)
+    rel = (a - b).abs() / (1.0 + a.abs())      # sigma_raw reaches -3000 in empty space: compare relatively
+    # trained weights cancel heavily, so single outputs move by O(1); the mean stays small and the
+    # rendered image moves by ~55 dB PSNR (see the GPU parity tests for the image-level bound)
+    assert float(rel.mean()) < 0.03 and float(rel.median()) < 0.01
+
+
+def test_adam_matches_torch():
+    torch.manual_seed(0)
+    p = torch.randn(1000); g = torch.randn(1000)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref], lr=5e-3)
+    m, v, q = torch.zeros(1000), torch.zeros(1000), p.clone()
+    for step in range(1, 4):
+        ref.grad = g.clone() * step
+        opt.step()
+        O.adam_step(q, g * step, m, v, step, 5e-3)
+    assert torch.allclose(q, ref.detach(), atol=1e-6)
