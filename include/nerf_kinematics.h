@@ -140,7 +140,7 @@ int nk_mse_loss(const float* rgb_coarse, const float* rgb_fine, const float* tar
                 void* stream);
 /* torch.optim.Adam update (the optimiser stored in the reference checkpoints) on flat buffers */
 int nk_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                 int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                 int64_t step, double lr, double beta1, double beta2, double eps, float grad_scale,
                  void* stream);
 
 /* ---- render_rays -------------------------------------------------------------------------- */

@@ -412,12 +412,12 @@ extern "C" int nk_mse_loss(const float* rgb_coarse, const float* rgb_fine, const
 }
 
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, int64_t n, float b1, float b2, float eps,
-                                              float step_size, float bc2_sqrt, float gscale) {
+                                              float* __restrict__ v, int64_t n, float omb1, float b2, float omb2,
+                                              float eps, float step_size, float bc2_sqrt, float gscale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
-        const float mi = m[i] + (1.0f - b1) * (gi - m[i]);            // exp_avg.lerp_(grad, 1 - beta1)
-        const float vi = __fadd_rn(__fmul_rn(v[i], b2), __fmul_rn(1.0f - b2, __fmul_rn(gi, gi)));
+        const float mi = m[i] + omb1 * (gi - m[i]);                   // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = __fadd_rn(__fmul_rn(v[i], b2), __fmul_rn(omb2, __fmul_rn(gi, gi)));   // mul_(b2).addcmul_(g, g, 1 - b2)
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         m[i] = mi; v[i] = vi;
         p[i] = p[i] - step_size * (mi / denom);
@@ -425,15 +425,16 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 }
 
 extern "C" int nk_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                            int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                            int64_t step, double lr, double beta1, double beta2, double eps, float grad_scale,
                             void* stream) {
     if (!params || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1)
         NK_FAIL(NK_ERR_ARG, "nk_adam_step: null pointer, n <= 0 or step < 1");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, nk_stream(stream), params, grad, exp_avg, exp_avg_sq, n,
-                       beta1, beta2, eps, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale);
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(lr / bc1),
+                       (float)sqrt(bc2), grad_scale);
     NK_CHECK_LAUNCH("k_adam");
     return NK_OK;
 }

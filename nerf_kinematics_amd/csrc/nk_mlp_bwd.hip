@@ -254,10 +254,11 @@ __global__ __launch_bounds__(512, 2) void k_dw_gemm(GemmArgs a) {
                     if (want_bias && ((2 * gi + ks) % a.WN) == wn) {
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
-                            const u32x4 u = __builtin_bit_cast(u32x4, af[i]);
 #pragma unroll
-                            for (int w = 0; w < 4; ++w)
-                                bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, u[w]), ones, bsum[i], false);
+                            for (int w = 0; w < 4; ++w) {
+                                bf16x2 pr; pr[0] = af[i][2 * w]; pr[1] = af[i][2 * w + 1];
+                                bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
+                            }
                         }
                     }
                 }

@@ -58,7 +58,7 @@ SIGNATURES = {
     "nk_dz_bytes": (_I64, [_PA, _I64, _I32]),
     "nk_mlp_backward": (C.c_int, [_PA, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "nk_mse_loss": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P, _P]),
-    "nk_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P]),
+    "nk_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I64, C.c_double, C.c_double, C.c_double, C.c_double, _F, _P]),
     "nk_render_workspace_bytes": (_I64, [_PA, _PA, _PO, _I64, C.c_int]),
     "nk_render_rays_fwd": (C.c_int, [_PA, _P, _PA, _P, _P, _I64, _PO, C.c_int, _P, _I64, _PR, _P]),
     "nk_render_rays_bwd": (C.c_int, [_PA, _P, _PA, _P, _P, _I64, _PO, _P, _I64, _P, _P, _P, _P, _P]),

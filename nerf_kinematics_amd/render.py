@@ -249,3 +249,59 @@ def render_rays(ray_batch: torch.Tensor, coarse: NeRFModel, fine: Optional[NeRFM
     flat_f = fine.flat if fine is not None else None
     res = _RenderRays.apply(rb, coarse.flat, flat_f, coarse, fine, opts, bool(training))
     return res[:6]
+
+
+# ---------------------------------------------------------------------------------------------
+# MLP backward, loss and optimiser (training-side stages)
+# ---------------------------------------------------------------------------------------------
+def alloc_activations(model: NeRFModel, R: int, n: int) -> torch.Tensor:
+    """Buffer ``run_network(..., act_save=...)`` fills for ``mlp_backward``."""
+    L = _lib.load()
+    nbytes = _lib.check(L.nk_act_bytes(model._c, R, n))
+    return torch.empty(nbytes, dtype=torch.uint8, device=model.flat.device)
+
+
+def mlp_backward(model: NeRFModel, act_save: torch.Tensor, d_raw: torch.Tensor,
+                 grad: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """grad (flat, fp32) += dL/dparams given dL/draw [R, n, 4] and the saved activations."""
+    L = _lib.load()
+    d_raw = _f32(d_raw, "d_raw", (None, None, 4))
+    R, n = d_raw.shape[0], d_raw.shape[1]
+    dev = d_raw.device
+    if grad is None:
+        grad = torch.zeros_like(model.flat)
+    dz = torch.empty(_lib.check(L.nk_dz_bytes(model._c, R, n)), dtype=torch.uint8, device=dev)
+    model.ensure_packed()
+    with torch.cuda.device(dev):
+        _lib.check(L.nk_mlp_backward(model._c, model.packed.data_ptr(), act_save.data_ptr(), d_raw.data_ptr(), R, n,
+                                     dz.data_ptr(), grad.data_ptr(), _stream(dev)))
+    return grad
+
+
+def mse_loss(rgb_coarse: Optional[torch.Tensor], rgb_fine: Optional[torch.Tensor], target: torch.Tensor,
+             grad_scale: float = 1.0):
+    """img2mse on both maps; returns (loss[1], d_rgb_coarse, d_rgb_fine)."""
+    L = _lib.load()
+    target = _f32(target, "target", (None, 3))
+    R, dev = target.shape[0], target.device
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    dc = torch.empty_like(target) if rgb_coarse is not None else None
+    df = torch.empty_like(target) if rgb_fine is not None else None
+    with torch.cuda.device(dev):
+        _lib.check(L.nk_mse_loss(_ptr(rgb_coarse), _ptr(rgb_fine), target.data_ptr(), R, float(grad_scale),
+                                 loss.data_ptr(), _ptr(dc), _ptr(df), _stream(dev)))
+    return loss, dc, df
+
+
+def adam_step(params: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
+              lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0) -> None:
+    """torch.optim.Adam's update on flat fp32 buffers, in place."""
+    L = _lib.load()
+    for name, t in (("params", params), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        _f32(t, name, (params.numel(),))
+        if not t.is_contiguous():
+            raise ValueError(f"{name}: must be contiguous")
+    with torch.cuda.device(params.device):
+        _lib.check(L.nk_adam_step(params.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                  params.numel(), int(step), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                  float(grad_scale), _stream(params.device)))

@@ -233,11 +233,25 @@ def _bf16r(x: torch.Tensor) -> torch.Tensor:
     return x + (r - x.detach())
 
 
+class _RoundGradBf16(torch.autograd.Function):
+    """Identity whose backward rounds the incoming gradient to bf16: the HIP backward keeps every
+    dL/d(pre-activation) as bf16 MFMA operands (fp32 accumulate)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
 class NeRFNet:
     """MLP evaluated from a dict of named tensors (``name.weight`` / ``name.bias``).
 
-    ``emulate_bf16``: round weights and every layer input to bf16 (fp32 accumulate, fp32 bias),
-    which is where the HIP MFMA path rounds; lets tests use a tight tolerance.
+    ``emulate_bf16``: round weights and every layer input to bf16 (fp32 accumulate, fp32 bias) and,
+    in backward, every dL/d(pre-activation); this is where the HIP MFMA path rounds, so tests can
+    use a tight tolerance.
     """
 
     def __init__(self, arch: Arch, params: Dict[str, torch.Tensor], emulate_bf16: bool = False):
@@ -280,6 +294,7 @@ class NeRFNet:
         w, b = self.p[name + ".weight"], self.p[name + ".bias"]
         if self.emu:
             w, x = _bf16r(w), _bf16r(x)
+            return _RoundGradBf16.apply(x @ w.t() + b)
         return x @ w.t() + b
 
     def __call__(self, x_enc: torch.Tensor, d_enc: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,157 @@
+"""GPU parity tests of the training half: MLP backward (chain + dW GEMM), render_rays gradients,
+loss and Adam, against autograd through the CPU oracle on the same inputs.
+
+Tolerance for bf16 gradients: the HIP path rounds weights, layer inputs and dZ to bf16 (fp32
+accumulate) and the oracle's emulation mode rounds at the same places; what is left is
+accumulation order and the occasional element that rounds the other way, so per-tensor relative
+L2 error is bounded at 3e-2.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nk():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU and the HIP library; there is no CPU fallback")
+    import nerf_kinematics_amd as nk
+    nk.load()
+    return nk
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def oarch(a):
+    return O.Arch(a.depth, a.width, a.skip, a.dir_width, a.n_freq_xyz, a.n_freq_dir, a.relu_first, a.relu_feat, a.lineage)
+
+
+def rays(R, seed):
+    g = torch.Generator().manual_seed(seed)
+    focal = 0.5 * 16 / math.tan(0.5 * 0.6911112070083618)
+    ro, rd = O.get_rays(16, 16, focal, O.spherical_pose(45.0, -30.0, 4.0))
+    rb = O.make_ray_batch(ro, rd, 2.0, 6.0)
+    return rb[torch.randperm(256, generator=g)[:R]].contiguous(), g
+
+
+def per_tensor_rel_err(arch, got, ref):
+    out, off = {}, 0
+    for name, (o, i) in arch.param_shapes():
+        for suffix, cnt in ((".weight", o * i), (".bias", o)):
+            a, b = got[off:off + cnt], ref[off:off + cnt]
+            out[name + suffix] = float((a - b).norm() / (b.norm() + 1e-12)), float(b.norm())
+            off += cnt
+    return out
+
+
+def check_grads(arch, got, ref, tol=3e-2):
+    errs = per_tensor_rel_err(arch, got.cpu(), ref)
+    total = float(ref.norm())
+    bad = {k: v for k, v in errs.items() if v[0] > tol and v[1] > 1e-6 * total}
+    assert not bad, bad
+    assert float((got.cpu() - ref).norm() / ref.norm()) < tol / 2
+
+
+@pytest.mark.parametrize("which,R,n", [("run_nerf", 12, 192), ("flexible", 20, 64), ("flexible_skip_rows", 5, 33)])
+def test_mlp_backward_matches_autograd(nk, dev, which, R, n):
+    arch = nk.ARCH_RUN_NERF if which == "run_nerf" else nk.ARCH_LEGO_CKPT
+    flat = O.NeRFNet.init_flat(oarch(arch), 7)
+    rb, g = rays(R, 11)
+    z = torch.sort(torch.rand(R, n, generator=g) * 4 + 2, -1)[0]
+    d_raw = torch.randn(R, n, 4, generator=g)
+    model = nk.NeRFModel(arch, flat.to(dev))
+    act = nk.alloc_activations(model, R, n)
+    raw = nk.run_network(model, rb.to(dev), z.to(dev), act_save=act)
+    grad = nk.mlp_backward(model, act, d_raw.to(dev))
+    fl = flat.clone().requires_grad_(True)
+    net = O.NeRFNet.from_flat(oarch(arch), fl, emulate_bf16=True)
+    ref_raw = O._run_net(net, rb, z)
+    (ref_raw * d_raw).sum().backward()
+    assert float((raw.cpu() - ref_raw.detach()).abs().max()) < 1e-2
+    check_grads(arch, grad, fl.grad)
+
+
+def test_mlp_backward_accumulates_and_is_linear(nk, dev):
+    """grad += semantics and linearity in d_raw (bf16 rounding commutes with a power-of-two scale)."""
+    arch = nk.ARCH_LEGO_CKPT
+    flat = O.NeRFNet.init_flat(oarch(arch), 3)
+    rb, g = rays(16, 5)
+    z = torch.sort(torch.rand(16, 64, generator=g) * 4 + 2, -1)[0]
+    d_raw = torch.randn(16, 64, 4, generator=g).to(dev)
+    model = nk.NeRFModel(arch, flat.to(dev))
+    act = nk.alloc_activations(model, 16, 64)
+    nk.run_network(model, rb.to(dev), z.to(dev), act_save=act)
+    g1 = nk.mlp_backward(model, act, d_raw)
+    g2 = nk.mlp_backward(model, act, d_raw * 2.0)
+    assert float((g2 - 2 * g1).norm() / g2.norm()) < 1e-5
+    g3 = nk.mlp_backward(model, act, d_raw, grad=g1.clone())
+    assert float((g3 - 2 * g1).norm() / g3.norm()) < 1e-5
+
+
+@pytest.mark.parametrize("which", ["flexible", "run_nerf"])
+def test_render_rays_gradients(nk, dev, which):
+    """Full render_rays (coarse + fine, perturb + noise) gradient of the NeRF loss."""
+    arch = nk.ARCH_RUN_NERF if which == "run_nerf" else nk.ARCH_LEGO_CKPT
+    R = 24 if which == "run_nerf" else 48
+    fc, ff = O.NeRFNet.init_flat(oarch(arch), 1), O.NeRFNet.init_flat(oarch(arch), 2)
+    # scale the density head up so rays are not uniformly transparent
+    rb, g = rays(R, 21)
+    target = torch.rand(R, 3, generator=g)
+    kw = dict(perturb=True, radiance_field_noise_std=0.2, seed=5)
+    c = nk.NeRFModel(arch, fc.to(dev)); f = nk.NeRFModel(arch, ff.to(dev))
+    c.flat.requires_grad_(True); f.flat.requires_grad_(True)
+    out = nk.render_rays(rb.to(dev), c, f, num_coarse=64, num_fine=128, **kw)
+    tg = target.to(dev)
+    loss = ((out[3] - tg) ** 2).mean() + ((out[0] - tg) ** 2).mean()
+    loss.backward()
+    fco, ffo = fc.clone().requires_grad_(True), ff.clone().requires_grad_(True)
+    co = O.NeRFNet.from_flat(oarch(arch), fco, emulate_bf16=True)
+    fo = O.NeRFNet.from_flat(oarch(arch), ffo, emulate_bf16=True)
+    ref = O.render_rays(rb, co, fo, O.RenderOpts(64, 128, **kw))
+    lref = O.nerf_loss(ref, target)
+    lref.backward()
+    assert abs(float(loss) - float(lref)) < 2e-3 * float(lref) + 1e-5
+    check_grads(arch, c.flat.grad, fco.grad, tol=5e-2)
+    check_grads(arch, f.flat.grad, ffo.grad, tol=5e-2)
+
+
+def test_mse_loss_kernel(nk, dev):
+    torch.manual_seed(0)
+    R = 1000
+    a, b, t = torch.rand(R, 3), torch.rand(R, 3), torch.rand(R, 3)
+    loss, dc, df = nk.mse_loss(a.to(dev), b.to(dev), t.to(dev))
+    ref = ((a - t) ** 2).mean() + ((b - t) ** 2).mean()
+    assert abs(float(loss) - float(ref)) < 1e-6
+    np.testing.assert_allclose(dc.cpu().numpy(), (2 * (a - t) / (3 * R)).numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(df.cpu().numpy(), (2 * (b - t) / (3 * R)).numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_adam_kernel_matches_torch_adam(nk, dev):
+    """Same update as the optimiser whose state the reference checkpoints store."""
+    torch.manual_seed(0)
+    n = 84548
+    p0 = torch.randn(n)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=5e-3)
+    p = p0.clone().to(dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    for step in range(1, 6):
+        g = torch.randn(n) * (0.1 * step)
+        ref.grad = g.clone()
+        for grp in opt.param_groups:
+            grp["lr"] = O.lr_at(step, 5e-3)
+        opt.step()
+        nk.adam_step(p, g.to(dev), m, v, step, O.lr_at(step, 5e-3))
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-7)
+    st = opt.state[ref]
+    np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-6, atol=3e-8)
+    np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-10)
