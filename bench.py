@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Throughput of the render_rays training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N == 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): synthetic lego at 400x400 -- views of the reference's trained
+lego checkpoint rendered by the HIP path are the "photographs" (the real nerf_synthetic images are
+not available offline) -- 64 coarse + 128 fine samples, coarse and fine 8x256 skip networks with
+torch.nn.Linear default init, bf16 MFMA compute with fp32 accumulate and fp32 master weights.
+One step = pick random pixels of one view, get_rays, render_rays forward, img2mse on both maps,
+backward, (all-reduce of the flat gradient), Adam, re-pack of the bf16 weight image.
+Every GPU takes --rays rays per step (weak scaling).  value = ray-samples/s = rays/s x (64+128),
+summed over all GPUs, inputs resident in HBM.
+
+Extra objects on the JSON line:
+  roofline      the fine-network fused MLP forward launch (k_mlp_fwd): algorithmic FLOPs per
+                launch / its mean duration from HIP events recorded around it in the timed steps
+  cpu_baseline  the CPU restatement (oracle, torch CPU fp32) of the same training step, timed on
+                this host on a bounded ray sample (rank 0, N == 1 only)
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_EVAL_8x256 = 1186816          # forward FLOPs of one 8x256 NeRF evaluation (2 x 593 408 MAC)
+PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=16384, help="rays per step per GPU")
+    ap.add_argument("--views", type=int, default=4, help="teacher views rendered for the synthetic dataset")
+    ap.add_argument("--res", type=int, default=400)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=192, help="rays in the CPU baseline sample")
+    return ap.parse_args()
+
+
+def teacher_views(nk, O, dev, n_views, res, rank):
+    """Render the synthetic dataset: the trained lego checkpoint seen from a ring of poses."""
+    w = np.load(os.path.join(ROOT, "tests", "golden", "lego_lowres3_weights.npz"))
+    c = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(w["coarse"]).to(dev))
+    f = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(w["fine"]).to(dev))
+    focal = 0.5 * res / math.tan(0.5 * 0.6911112070083618)
+    imgs, poses = [], []
+    for k in range(n_views):
+        theta = 360.0 * (k + 0.37 * rank) / n_views
+        phi = -30.0 + 15.0 * math.sin(2 * math.pi * k / max(n_views, 1))
+        c2w = O.spherical_pose(theta, phi, 4.0)
+        rb = nk.get_rays(res, res, focal, c2w, near=2.0, far=6.0, device=dev)
+        with torch.no_grad():
+            parts = [nk.render_rays(rb[s:s + 65536], c, f, num_coarse=64, num_fine=128)[0]
+                     for s in range(0, rb.shape[0], 65536)]
+        imgs.append(torch.cat(parts).clamp(0, 1))
+        poses.append(c2w)
+    return imgs, poses, focal
+
+
+def cpu_baseline(O, rays, seed=0):
+    """One training step of the CPU restatement on `rays` rays (8x256 pair, 64+128), median of 3."""
+    torch.manual_seed(seed)
+    arch = O.ARCH_RUN_NERF
+    fc = O.NeRFNet.init_flat(arch, 42).requires_grad_(True)
+    ff = O.NeRFNet.init_flat(arch, 43).requires_grad_(True)
+    focal = 0.5 * 400 / math.tan(0.5 * 0.6911112070083618)
+    ro, rd = O.get_rays(400, 400, focal, O.spherical_pose(45.0, -30.0, 4.0))
+    rb = O.make_ray_batch(ro, rd, 2.0, 6.0)
+    sel = torch.randperm(rb.shape[0])[:rays]
+    rb = rb[sel].contiguous()
+    target = torch.rand(rays, 3)
+    opt = torch.optim.Adam([fc, ff], lr=5e-4)
+    times = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        co, fo = O.NeRFNet.from_flat(arch, fc), O.NeRFNet.from_flat(arch, ff)
+        out = O.render_rays(rb, co, fo, O.RenderOpts(64, 128, perturb=True, radiance_field_noise_std=0.2, seed=it))
+        loss = O.nerf_loss(out, target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return rays * 192 / t, t
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    import nerf_kinematics_amd as nk
+    from nerf_kinematics_amd.trainer import Trainer, TrainOpts
+    from oracle import nerf_oracle as O        # cpu_baseline leg + pose helper only
+
+    imgs, poses, focal = teacher_views(nk, O, dev, a.views, a.res, rank)
+    opts = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=a.rays, perturb=True,
+                     radiance_field_noise_std=0.2, lr=5e-4, seed=42)
+    tr = Trainer(nk.ARCH_RUN_NERF, nk.ARCH_RUN_NERF, opts, dev, rays_per_step=a.rays)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    npix = a.res * a.res
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    dummy = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def one_step(i, events):
+        v = i % len(imgs)
+        pix = torch.randint(0, npix, (a.rays,), generator=gen, device=dev, dtype=torch.int32)
+        rb = nk.get_rays(a.res, a.res, focal, poses[v], near=2.0, far=6.0, pixels=pix)
+        target = imgs[v][pix.long()]
+        return tr.step(rb, target, events=events)
+
+    for i in range(a.warmup):
+        one_step(i, dummy)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = one_step(a.warmup + i, ev[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        samples = a.rays * 192 * a.steps * world
+        value = samples / dt
+        # dominant kernel: fused MLP forward of the fine network (192 evaluations per ray)
+        k_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+        flops = a.rays * 192 * FLOP_PER_EVAL_8x256
+        achieved = flops / (k_ms * 1e-3) / 1e12
+        res = {
+            "metric": "ray-samples/sec (train)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"lego-teacher {a.res}x{a.res}, 64 coarse + 128 fine, 8x256 coarse+fine NeRF, "
+                                   f"train step (fwd+bwd+Adam), {a.rays} rays/step/GPU",
+                       "rays_per_step_per_gpu": a.rays, "num_coarse": 64, "num_fine": 128,
+                       "mlp_evals_per_s": value / 192 * 256, "final_loss": float(loss)},
+            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<256,128> (fine network, 192 evals/ray)",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "kernel_ms": k_ms,
+                         "flop_per_launch": flops,
+                         "step_train_tflops": samples / dt * 3 * FLOP_PER_EVAL_8x256 * 256 / 192 / 1e12},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+            v, t = cpu_baseline(O, a.cpu_rays)
+            res["cpu_baseline"] = {"value": v, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
+                                   "kind": "port",
+                                   "sample": f"{a.cpu_rays} rays x (64+128) samples, one training step "
+                                             f"(fwd+bwd+Adam) of the torch-CPU fp32 restatement, median of 3 "
+                                             f"after 1 warm-up, {t:.2f} s/step"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

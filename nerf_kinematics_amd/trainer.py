@@ -1,0 +1,234 @@
+"""Training step around the HIP render path: render_rays forward, img2mse, backward, gradient
+all-reduce (RCCL when world_size > 1), Adam with the reference's exponential learning-rate decay,
+re-pack of the bf16 weight image.
+
+The loop structure and every constant follow the reference's experiment files
+(/root/reference/trained_models/nerf-pytorch/lego-lowres3/config.yml): ``experiment`` block
+(:10-17, train_iters / validate_every / save_every / randomseed), ``nerf.train`` block (:46-54),
+``optimizer`` and ``scheduler`` (:64-69).  The learning rate is
+``lr0 * lr_decay_factor ** (iter / (lr_decay * 1000))`` which reproduces the value stored in both
+vendored checkpoints.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+
+from . import lib as _lib
+from .model import Arch, NeRFModel
+from .render import make_opts, _ptr, _stream
+
+
+@dataclass
+class TrainOpts:
+    """``nerf.train`` + ``optimizer`` + ``scheduler`` of a reference config.yml."""
+    num_coarse: int = 64
+    num_fine: int = 128
+    num_random_rays: int = 1024
+    perturb: bool = True
+    lindisp: bool = False
+    radiance_field_noise_std: float = 0.2
+    white_background: bool = False
+    lr: float = 5e-3
+    lr_decay: int = 250
+    lr_decay_factor: float = 0.1
+    betas: tuple = (0.9, 0.999)
+    eps: float = 1e-8
+    seed: int = 42
+
+    @staticmethod
+    def from_config(cfg: dict) -> "TrainOpts":
+        t = cfg.get("nerf", {}).get("train", {})
+        o, s = cfg.get("optimizer", {}), cfg.get("scheduler", {})
+        return TrainOpts(num_coarse=int(t.get("num_coarse", 64)), num_fine=int(t.get("num_fine", 128)),
+                         num_random_rays=int(t.get("num_random_rays", 1024)), perturb=bool(t.get("perturb", True)),
+                         lindisp=bool(t.get("lindisp", False)),
+                         radiance_field_noise_std=float(t.get("radiance_field_noise_std", 0.0)),
+                         white_background=bool(t.get("white_background", False)), lr=float(o.get("lr", 5e-4)),
+                         lr_decay=int(s.get("lr_decay", 250)), lr_decay_factor=float(s.get("lr_decay_factor", 0.1)),
+                         seed=int(cfg.get("experiment", {}).get("randomseed", 42)))
+
+
+def lr_at(iteration: int, o: TrainOpts) -> float:
+    return o.lr * (o.lr_decay_factor ** (iteration / (o.lr_decay * 1000)))
+
+
+class Trainer:
+    """Owns both networks (one flat parameter / gradient / Adam-state buffer for the pair, so a
+    data-parallel step is ONE all-reduce) and a workspace sized for ``rays_per_step`` rays."""
+
+    def __init__(self, arch_coarse: Arch, arch_fine: Optional[Arch], opts: TrainOpts, device,
+                 rays_per_step: Optional[int] = None, init_seed: Optional[int] = None,
+                 process_group=None):
+        self.L = _lib.load()
+        self.opts = opts
+        self.device = torch.device(device)
+        self.R = int(rays_per_step or opts.num_random_rays)
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if (
+            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        seed = opts.seed if init_seed is None else init_seed
+        use_fine = opts.num_fine > 0 and arch_fine is not None
+        nc = arch_coarse.num_params()
+        nf = arch_fine.num_params() if use_fine else 0
+        nc_pad = (nc + 63) // 64 * 64          # keep the fine block 256-byte aligned
+        self.params = torch.zeros(nc_pad + nf, dtype=torch.float32, device=self.device)
+        self.params[:nc] = _init_flat(arch_coarse, seed).to(self.device)
+        if use_fine:
+            self.params[nc_pad:] = _init_flat(arch_fine, seed + 1).to(self.device)
+        self.grad = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.coarse = NeRFModel(arch_coarse, self.params[:nc])
+        self.fine = NeRFModel(arch_fine, self.params[nc_pad:]) if use_fine else None
+        self._nc, self._nc_pad = nc, nc_pad
+        self.iteration = 0
+        self._alloc(self.R)
+
+    # -- buffers ----------------------------------------------------------------------------
+    def _alloc(self, R: int) -> None:
+        o = self.opts
+        self.ropts = make_opts(o.num_coarse, o.num_fine if self.fine is not None else 0, o.perturb, o.lindisp,
+                               o.radiance_field_noise_std, o.white_background, o.seed)
+        fc = self.fine._c if self.fine is not None else None
+        self.ws_bytes = _lib.check(self.L.nk_render_workspace_bytes(self.coarse._c, fc, self.ropts, R, 1))
+        self.ws = None              # allocated on the first non-staged step
+        mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+        self.rgb_c, self.rgb_f = mk(R, 3), (mk(R, 3) if self.fine is not None else None)
+        self.d_rgb_c, self.d_rgb_f = mk(R, 3), (mk(R, 3) if self.fine is not None else None)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.out = _lib.NkRenderOut(_ptr(self.rgb_f), None, None, None, _ptr(self.rgb_c), None, None, None)
+
+    def grad_views(self):
+        gc = self.grad[:self._nc]
+        gf = self.grad[self._nc_pad:] if self.fine is not None else None
+        return gc, gf
+
+    # -- one optimisation step -----------------------------------------------------------------
+    def _forward_staged(self, ray_batch, R, st, events):
+        """The kernel sequence of nk_render_rays_fwd issued stage by stage, so that HIP events can
+        bracket the fine-network MLP launch on the stream it runs on (used by bench.py)."""
+        L, o = self.L, self.ropts
+        Nc, Nf = o.num_coarse, o.num_fine
+        if not hasattr(self, "_stage"):
+            mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+            acts = lambda m, n: torch.empty(_lib.check(L.nk_act_bytes(m._c, R, n)), dtype=torch.uint8, device=self.device)
+            self._stage = dict(z_c=mk(R, Nc), raw_c=mk(R, Nc, 4), w_c=mk(R, Nc), act_c=acts(self.coarse, Nc),
+                               z_all=mk(R, Nc + Nf), raw_f=mk(R, Nc + Nf, 4), act_f=acts(self.fine, Nc + Nf),
+                               d_raw=mk(R, Nc + Nf, 4),
+                               dz=torch.empty(_lib.check(L.nk_dz_bytes(self.fine._c, R, Nc + Nf)), dtype=torch.uint8,
+                                              device=self.device))
+        s = self._stage
+        rb = ray_batch.data_ptr()
+        _lib.check(L.nk_stratified_z(rb, R, o, s["z_c"].data_ptr(), st))
+        _lib.check(L.nk_mlp_forward(self.coarse._c, self.coarse.packed.data_ptr(), rb, s["z_c"].data_ptr(), R, Nc,
+                                    s["raw_c"].data_ptr(), s["act_c"].data_ptr(), st))
+        _lib.check(L.nk_raw2outputs(s["raw_c"].data_ptr(), s["z_c"].data_ptr(), rb, R, Nc, o, _lib.STREAM_NOISE_COARSE,
+                                    self.rgb_c.data_ptr(), None, None, None, s["w_c"].data_ptr(), st))
+        _lib.check(L.nk_sample_pdf(s["z_c"].data_ptr(), s["w_c"].data_ptr(), R, o, s["z_all"].data_ptr(), None, st))
+        events[0].record()
+        _lib.check(L.nk_mlp_forward(self.fine._c, self.fine.packed.data_ptr(), rb, s["z_all"].data_ptr(), R, Nc + Nf,
+                                    s["raw_f"].data_ptr(), s["act_f"].data_ptr(), st))
+        events[1].record()
+        _lib.check(L.nk_raw2outputs(s["raw_f"].data_ptr(), s["z_all"].data_ptr(), rb, R, Nc + Nf, o,
+                                    _lib.STREAM_NOISE_FINE, self.rgb_f.data_ptr(), None, None, None, None, st))
+
+    def _backward_staged(self, ray_batch, R, st):
+        L, o, s = self.L, self.ropts, self._stage
+        Nc, Nf = o.num_coarse, o.num_fine
+        rb = ray_batch.data_ptr()
+        gc, gf = self.grad_views()
+        _lib.check(L.nk_raw2outputs_bwd(s["raw_f"].data_ptr(), s["z_all"].data_ptr(), rb, R, Nc + Nf, o,
+                                        _lib.STREAM_NOISE_FINE, self.d_rgb_f.data_ptr(), None, None,
+                                        s["d_raw"].data_ptr(), st))
+        _lib.check(L.nk_mlp_backward(self.fine._c, self.fine.packed.data_ptr(), s["act_f"].data_ptr(),
+                                     s["d_raw"].data_ptr(), R, Nc + Nf, s["dz"].data_ptr(), gf.data_ptr(), st))
+        _lib.check(L.nk_raw2outputs_bwd(s["raw_c"].data_ptr(), s["z_c"].data_ptr(), rb, R, Nc, o,
+                                        _lib.STREAM_NOISE_COARSE, self.d_rgb_c.data_ptr(), None, None,
+                                        s["d_raw"].data_ptr(), st))
+        _lib.check(L.nk_mlp_backward(self.coarse._c, self.coarse.packed.data_ptr(), s["act_c"].data_ptr(),
+                                     s["d_raw"].data_ptr(), R, Nc, s["dz"].data_ptr(), gc.data_ptr(), st))
+
+    def step(self, ray_batch: torch.Tensor, target: torch.Tensor, events=None) -> torch.Tensor:
+        """ray_batch [R,11], target [R,3] on this GPU; returns the loss tensor (device, no sync).
+
+        ``events``: optional (start, stop) torch.cuda.Event pair recorded around the fine-network MLP
+        forward launch; the step then issues the same kernels stage by stage."""
+        L, dev = self.L, self.device
+        R = ray_batch.shape[0]
+        if R != self.R:
+            raise ValueError(f"Trainer was sized for {self.R} rays per step, got {R}")
+        st = _stream(dev)
+        self.ropts.seed = (self.opts.seed + 0x9E3779B1 * (self.iteration + 1) + 7919 * self._rank()) & 0xFFFFFFFF
+        fc = self.fine._c if self.fine is not None else None
+        fp = self.fine.packed.data_ptr() if self.fine is not None else None
+        staged = events is not None and self.fine is not None
+        if not staged and self.ws is None:
+            self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
+            self.ws_ptr = (self.ws.data_ptr() + 255) & ~255
+        with torch.cuda.device(dev):
+            if staged:
+                self._forward_staged(ray_batch, R, st, events)
+            else:
+                _lib.check(L.nk_render_rays_fwd(self.coarse._c, self.coarse.packed.data_ptr(), fc, fp,
+                                                ray_batch.data_ptr(), R, self.ropts, 1, self.ws_ptr, self.ws_bytes,
+                                                self.out, st))
+            self.loss.zero_()
+            _lib.check(L.nk_mse_loss(self.rgb_c.data_ptr(), _ptr(self.rgb_f), target.data_ptr(), R, 1.0,
+                                     self.loss.data_ptr(), self.d_rgb_c.data_ptr(), _ptr(self.d_rgb_f), st))
+            self.grad.zero_()
+            gc, gf = self.grad_views()
+            if staged:
+                self._backward_staged(ray_batch, R, st)
+            else:
+                _lib.check(L.nk_render_rays_bwd(self.coarse._c, self.coarse.packed.data_ptr(), fc, fp,
+                                                ray_batch.data_ptr(), R, self.ropts, self.ws_ptr, self.ws_bytes,
+                                                _ptr(self.d_rgb_f), self.d_rgb_c.data_ptr(), gc.data_ptr(), _ptr(gf), st))
+            if self.world > 1:
+                torch.distributed.all_reduce(self.grad, group=self.pg)   # one flat buffer, both networks
+            self.iteration += 1
+            _lib.check(L.nk_adam_step(self.params.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                      self.exp_avg_sq.data_ptr(), self.params.numel(), self.iteration,
+                                      lr_at(self.iteration - 1, self.opts), self.opts.betas[0], self.opts.betas[1],
+                                      self.opts.eps, 1.0 / self.world, st))
+            self.coarse.pack()
+            if self.fine is not None:
+                self.fine.pack()
+        return self.loss
+
+    def _rank(self) -> int:
+        return torch.distributed.get_rank(self.pg) if self.world > 1 else 0
+
+    # -- inference --------------------------------------------------------------------------
+    @torch.no_grad()
+    def render(self, ray_batch: torch.Tensor, chunk: int = 65536, opts: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        """Whole-image render with the ``nerf.validation`` settings (no jitter, no noise)."""
+        from .render import render_rays
+        o = self.opts
+        kw = dict(num_coarse=o.num_coarse, num_fine=o.num_fine if self.fine is not None else 0, perturb=False,
+                  lindisp=o.lindisp, radiance_field_noise_std=0.0, white_background=o.white_background)
+        if opts:
+            kw.update(opts)
+        parts = []
+        for s in range(0, ray_batch.shape[0], chunk):
+            parts.append(render_rays(ray_batch[s:s + chunk], self.coarse, self.fine, training=False, **kw))
+        names = ("rgb_fine", "disp_fine", "acc_fine", "rgb_coarse", "disp_coarse", "acc_coarse")
+        return {n: torch.cat([p[i] for p in parts]) for i, n in enumerate(names)}
+
+
+def _init_flat(arch: Arch, seed: int) -> torch.Tensor:
+    """torch.nn.Linear default init, U(-1/sqrt(in), 1/sqrt(in)), in state-dict order."""
+    g = torch.Generator().manual_seed(seed)
+    parts = []
+    for _, (o, i) in arch.param_shapes():
+        b = 1.0 / math.sqrt(i)
+        parts.append((torch.rand(o * i, generator=g) * 2 - 1) * b)
+        parts.append((torch.rand(o, generator=g) * 2 - 1) * b)
+    return torch.cat(parts)
+
+
+def psnr_from_mse(mse: float) -> float:
+    return -10.0 * math.log10(max(mse, 1e-12))
