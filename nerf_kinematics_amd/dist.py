@@ -1,0 +1,48 @@
+"""Data-parallel helpers: rays shard across ranks, the only exchange is ONE all-reduce of the flat
+gradient buffer that holds both networks (RCCL on GPUs via backend "nccl"; gloo in CPU tests).
+The reference is single-GPU (no torch.distributed call site anywhere in /root/reference); this is
+the new capability the north star asks for."""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; initialises the process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {"device_id": torch.device(f"cuda:{local}")} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def shard_rows(n: int, rank: int, world: int) -> slice:
+    """Rows rank::world of a common batch (used by the 1-vs-N gradient equality test)."""
+    return slice(rank, n, world)
+
+
+def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum the flat gradient over ranks in place; the Adam kernel divides by world size."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+def params_in_sync(flat: torch.Tensor, group=None) -> bool:
+    """True when every rank holds bit-identical parameters (checked after optimiser steps)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return True
+    lo, hi = flat.clone(), flat.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(torch.equal(lo, hi))

@@ -1,0 +1,83 @@
+"""World-size-2 gloo test of the data-parallel contract (CPU; the oracle stands in for the GPU
+compute): summing per-rank gradients of the per-rank mean loss and dividing by the world size
+equals the single-process gradient on the concatenated batch, and identical updates keep the
+parameters bit-identical on every rank."""
+import math
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import nerf_oracle as O
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _batch(R=16):
+    focal = 0.5 * 16 / math.tan(0.5 * 0.6911112070083618)
+    ro, rd = O.get_rays(16, 16, focal, O.spherical_pose(45.0, -30.0, 4.0))
+    rb = O.make_ray_batch(ro, rd, 2.0, 6.0).view(16, 16, 11)[6:10, 6:10].reshape(-1, 11)[:R].contiguous()   # rays through the object
+    torch.manual_seed(1)
+    return rb, torch.rand(R, 3)
+
+
+def _weights():
+    import numpy as np
+    w = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lego_lowres3_weights.npz"))
+    return torch.from_numpy(w["coarse"]), torch.from_numpy(w["fine"])     # trained: the rays hit density
+
+
+def _grad(rb, target, flat_c, flat_f):
+    fc, ff = flat_c.clone().requires_grad_(True), flat_f.clone().requires_grad_(True)
+    a = O.ARCH_LEGO_CKPT
+    out = O.render_rays(rb, O.NeRFNet.from_flat(a, fc), O.NeRFNet.from_flat(a, ff), O.RenderOpts(16, 16))
+    O.nerf_loss(out, target).backward()
+    return torch.cat([fc.grad, ff.grad])
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from nerf_kinematics_amd import dist as nd
+    r, w, _ = nd.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    rb, target = _batch()
+    fc, ff = _weights()
+    sl = nd.shard_rows(rb.shape[0], rank, world)
+    g = _grad(rb[sl], target[sl], fc, ff)
+    nd.allreduce_sum_(g)
+    g /= world
+    params = torch.cat([fc, ff])
+    m, v = torch.zeros_like(params), torch.zeros_like(params)
+    O.adam_step(params, g, m, v, 1, 5e-3)
+    ok = nd.params_in_sync(params)
+    if rank == 0:
+        q.put((g.numpy().copy(), ok))     # by value: the worker's shared memory dies with it
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_equals_single_process():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g2, ok = q.get(timeout=300)
+    g2 = torch.from_numpy(g2)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    rb, target = _batch()
+    fc, ff = _weights()
+    g1 = _grad(rb, target, fc, ff)
+    assert ok
+    assert float(g1.norm()) > 0
+    assert float((g1 - g2).norm() / g1.norm()) < 1e-5
