@@ -119,6 +119,15 @@ NK_HD int64_t nk_act_offset(const NkPlan& p, int idx, int64_t G) {   // bytes
 }
 NK_HD int nk_act_count(const NkPlan& p) { return p.D + 4; }
 
+// ReLU masks, one 16-byte word per lane per layer ([G][64 lanes][4 dwords]), stored after the
+// activation regions: idx 0..D-1 = h_i, D = feat, D+1 = g.  Bit 31 - (16*(t&1) + i) of dword t>>1
+// is set when accumulator register i of output tile t passes its gradient (sign bit of the
+// pre-activation clear, or the layer has no ReLU).
+NK_HD int nk_mask_count(const NkPlan& p) { return p.D + 2; }
+NK_HD int64_t nk_mask_offset(const NkPlan& p, int idx, int64_t G) {
+    return nk_act_offset(p, nk_act_count(p), G) + (int64_t)idx * G * 1024;
+}
+
 // dZ regions written by the backward chain: 0 = dOut (32: dr,dg,db,dsigma), 1 = dZ_views (WD),
 // 2 = dZ_feat (W), 3+i = dZ of trunk layer D-1-i (W)
 NK_HD int nk_dz_width(const NkPlan& p, int idx) {
@@ -139,3 +148,7 @@ static inline int64_t nk_groups(int64_t P) { return ((P + 255) / 256) * 8; }
 int nk_build_plan(const nk_arch* arch, NkPlan* plan);   // host; returns nk_status
 
 static inline hipStream_t nk_stream(void* s) { return (hipStream_t)s; }
+
+// Wavefronts per workgroup of the MLP chain kernels (4: two workgroups share a CU and run out of
+// phase; 8: one workgroup per CU streams the weights once for 256 points).  NK_WAVES overrides.
+int nk_waves_per_wg();

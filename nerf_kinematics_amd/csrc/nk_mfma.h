@@ -61,8 +61,9 @@ NK_D void pe_dir_frags(float dx, float dy, float dz, int h, Frag (&f)[2]) {
 }
 
 // The weight stream: stage i sits in ring half (i & 1); a stage is loaded while the previous one
-// is consumed.  All 8 waves issue the loads (block b by wave b % 8) and all pass one barrier per
+// is consumed.  All NW waves issue the loads (block b by wave b % NW) and all pass one barrier per
 // stage, which both publishes the landed stage and retires the reads of the one being replaced.
+template <int NW>
 struct WStream {
     const char* g;      // next byte of the stream to load
     char* ring;         // LDS base
@@ -71,7 +72,7 @@ struct WStream {
     int wave, lane;
     NK_D void issue(int nb) {        // load the next stage (nb blocks) into the other half
         char* dst = ring + (cur ^ 1) * half_bytes;
-        for (int b = wave; b < nb; b += 8)
+        for (int b = wave; b < nb; b += NW)
             __builtin_amdgcn_global_load_lds((const NK_GLB void*)(g + (int64_t)b * 1024 + lane * 16),
                                              (NK_LDS void*)(dst + b * 1024), 16, 0, 0);
         g += (int64_t)nb * 1024;
@@ -79,6 +80,23 @@ struct WStream {
     NK_D void flip() {               // end of stage: loaded data visible, old half free
         __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
         __syncthreads();
+        cur ^= 1;
+    }
+    // Same, but lets the NST youngest vector-memory operations stay in flight.  vmcnt retires in
+    // issue order, so when the only operations issued after this stage's issue() are NST global
+    // STORES (activation / dZ tiles, which the compiler cannot move above the stream load they may
+    // alias), the stream load has landed once at most NST operations are outstanding.  Passing a
+    // smaller NST than the true count only waits longer; a larger one would race.
+    template <int NST>
+    NK_D void flip_keep() {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NST) : "memory");
+        cur ^= 1;
+    }
+    // Same, naming the tile's accumulator: its MFMAs are register-only instructions that hipcc
+    // otherwise sinks below the barrier, stretching the live range of 16 weight fragments.
+    template <int NST>
+    NK_D void flip_keep(f32x16& acc) {
+        asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)\n\ts_barrier" : "+v"(acc) : "n"(NST) : "memory");
         cur ^= 1;
     }
     NK_D const char* stage() const { return ring + cur * half_bytes; }
@@ -96,14 +114,40 @@ NK_D f32x16 lds_bias(const char* stage, int nk, int h) {
     return v;
 }
 
-template <int NK>
-NK_D f32x16 tile_mfma(f32x16 acc, const char* stage, int blk0, const Frag* bf, int lane) {
+// One 32-row output tile: NK0 k-steps against fragments b0[], then NK1 against b1[].  The A
+// fragments come from LDS with an explicit 8-deep read-ahead so the MFMA chain never waits on a
+// just-issued ds_read.
+template <int NK0, int NK1, int NPRE = 0>   // NPRE: other LDS reads issued just before (the bias fragment)
+NK_D f32x16 tile_run(f32x16 acc, const char* stage, int lane, const Frag* b0, const Frag* b1) {
+    constexpr int NK = NK0 + NK1;
+#ifndef NK_LOOKAHEAD
+#define NK_LOOKAHEAD 8
+#endif
+    constexpr int LA = NK < NK_LOOKAHEAD ? NK : NK_LOOKAHEAD;
+    const char* base = stage + lane * 16;
+    bf16x8 a[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) a[i] = *(const bf16x8*)(base + i * 1024);
+    // pin the software pipeline: LA reads up front, then one MFMA / one read alternately
+    // (mask 0x100 = DS read, 0x008 = MFMA); without this the scheduler sinks each read to its use
+    __builtin_amdgcn_sched_group_barrier(0x100, LA + NPRE, 0);
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-        const bf16x8 a = *(const bf16x8*)(stage + (blk0 + ks) * 1024 + lane * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[ks].b, acc, 0, 0, 0);
+        const bf16x8 b = ks < NK0 ? b0[ks < NK0 ? ks : 0].b : b1[ks >= NK0 ? ks - NK0 : 0].b;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % LA], b, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (ks + LA < NK) {
+            a[ks % LA] = *(const bf16x8*)(base + (ks + LA) * 1024);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
     }
     return acc;
+}
+
+// Pin two fragments: everything that computes them is emitted before this point (keeps the
+// mask / convert of a finished tile ahead of the next stream load instead of being sunk below it).
+NK_D void pin_frags(Frag& f0, Frag& f1) {
+    asm volatile("" : "+v"(f0.u), "+v"(f1.u) : : "memory");
 }
 
 // store one bf16 activation tile: octets 4t..4t+3 of region `dst` ([G][NO][32][8] bf16)
@@ -114,6 +158,29 @@ NK_D void save_tile(char* dst, int64_t grp, int NO, int t, int c, int h, const F
     *(u32x2*)(base + 1 * 512) = u32x2{f0.u[2], f0.u[3]};
     *(u32x2*)(base + 2 * 512) = u32x2{f1.u[0], f1.u[1]};
     *(u32x2*)(base + 3 * 512) = u32x2{f1.u[2], f1.u[3]};
+}
+
+NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1);
+
+// Accumulator tile -> bf16 fragments (ReLU when `relu`), shifting the SIGN bit of each
+// pre-activation into `mw`, one v_alignbit per register (first register ends up highest).
+// The forward kernel stores ~mw for a ReLU layer (all ones otherwise) as the layer's
+// pass-gradient word: a gradient passes where the pre-activation's sign bit is clear.  That is
+// relu'(x) everywhere except at x == +0 exactly, where torch blocks the gradient.
+template <bool MASK>
+NK_D void acc_to_frags_mask(const f32x16& a, bool relu, Frag& f0, Frag& f1, uint32_t& mw) {
+    if (!MASK) { acc_to_frags(a, relu, f0, f1); return; }
+    // (never __builtin_bit_cast a vector ELEMENT: hipcc reads the wrong lane of it)
+    // registers are visited in index order 0..15 so that bit 31-k of the word belongs to register k
+    uint32_t m = mw;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float x = a[i];
+        m = __builtin_amdgcn_alignbit(m, (uint32_t)__float_as_int(x), 31);     // (m << 1) | sign(x)
+    }
+    asm volatile("" : "+v"(m));     // computed here: otherwise it is sunk to the layer's end and
+    mw = m;                         // keeps every accumulator tile of the layer alive (spills)
+    acc_to_frags(a, relu, f0, f1);
 }
 
 NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1) {

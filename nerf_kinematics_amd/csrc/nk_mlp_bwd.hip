@@ -21,134 +21,8 @@ struct BwdArgs {
     int64_t P, G;
 };
 
-// dZ tile = accumulator masked by (saved activation > 0), as bf16 fragments
-NK_D void mask_to_frags(const f32x16& a, const char* act_region, bool use_mask, int64_t grp, int NO, int t,
-                        int c, int h, Frag& f0, Frag& f1) {
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = a[i];
-    if (use_mask) {
-        const char* base = act_region + ((grp * NO + 4 * t) * 32 + c) * 16 + 8 * h;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u32x2 m = *(const u32x2*)(base + q * 512);
-            if ((m[0] & 0xFFFFu) == 0) v[4 * q + 0] = 0.0f;
-            if ((m[0] >> 16) == 0) v[4 * q + 1] = 0.0f;
-            if ((m[1] & 0xFFFFu) == 0) v[4 * q + 2] = 0.0f;
-            if ((m[1] >> 16) == 0) v[4 * q + 3] = 0.0f;
-        }
-    }
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        f0.u[w] = pack_bf16(v[2 * w], v[2 * w + 1]);
-        f1.u[w] = pack_bf16(v[8 + 2 * w], v[8 + 2 * w + 1]);
-    }
-}
+#include "nk_bwd_chain.inc"
 
-template <int W, int WD>
-__global__ __launch_bounds__(512, 2) void k_mlp_bwd(BwdArgs a) {
-    constexpr int NT = W / 32, NKT = W / 16, NTD = WD / 32, NKD = WD / 16;
-    constexpr int HALF = (NKT + 1) * 1024;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const NkPlan& p = a.plan;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const int64_t grp = (int64_t)blockIdx.x * 8 + wave;
-    const int64_t pt = grp * 32 + c;
-    const bool valid = pt < a.P;
-    const int D = p.D;
-    constexpr int NOW = W / 8, NOD = WD / 8;
-    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-    WStream ws;
-    ws.g = a.packed_t; ws.ring = lds; ws.half_bytes = HALF; ws.cur = 1; ws.wave = wave; ws.lane = lane;
-    ws.issue(1);
-    ws.flip();
-
-    // dOut fragment: k-slots 0..3 = d(rgb_raw), d(sigma_raw)
-    Frag dout, zf;
-    zf.u = u32x4{0, 0, 0, 0};
-    dout.u = zf.u;
-    if (valid && h == 0) {
-        const float4 d = *(const float4*)(a.d_raw + pt * 4);
-        dout.u[0] = pack_bf16(d.x, d.y);
-        dout.u[1] = pack_bf16(d.z, d.w);
-    }
-    save_tile(a.dz + nk_dz_offset(p, 0, a.G), grp, 4, 0, c, h, dout, zf);
-
-    f32x16 acc[NT];
-    Frag hb[2 * NT];
-    Frag gb[2 * NTD];
-
-    // ---- RGB^T: dG = Wrgb^T dOut, masked by g > 0 -> dZ_views ------------------------------
-#pragma unroll
-    for (int t = 0; t < NTD; ++t) {
-        ws.issue((t + 1 < NTD) ? 1 : NKD);
-        acc[t] = tile_mfma<1>(zero16, ws.stage(), 0, &dout, lane);
-        ws.flip();
-    }
-    {
-        const char* msk = a.act + nk_act_offset(p, 3 + D, a.G);
-        char* dst = a.dz + nk_dz_offset(p, 1, a.G);
-#pragma unroll
-        for (int t = 0; t < NTD; ++t) {
-            mask_to_frags(acc[t], msk, true, grp, NOD, t, c, h, gb[2 * t], gb[2 * t + 1]);
-            save_tile(dst, grp, NOD, t, c, h, gb[2 * t], gb[2 * t + 1]);
-        }
-    }
-    // ---- VIEWS^T: dFeat = Wv[:, :W]^T dZ_views -> dZ_feat ------------------------------------
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        ws.issue((t + 1 < NT) ? NKD : NKT + 1);
-        acc[t] = tile_mfma<NKD>(zero16, ws.stage(), 0, gb, lane);
-        ws.flip();
-    }
-    {
-        const char* msk = a.act + nk_act_offset(p, 2 + D, a.G);
-        char* dst = a.dz + nk_dz_offset(p, 2, a.G);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            mask_to_frags(acc[t], msk, p.relu_feat != 0, grp, NOW, t, c, h, hb[2 * t], hb[2 * t + 1]);
-            save_tile(dst, grp, NOW, t, c, h, hb[2 * t], hb[2 * t + 1]);
-        }
-    }
-    // ---- FEAT^T (+ alpha row): dH_{D-1} = Wfeat^T dZ_feat + walpha^T dsigma -> dZ_{D-1} -------
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        ws.issue((t + 1 < NT) ? NKT + 1 : NKT);
-        const char* st = ws.stage();
-        const f32x16 v = tile_mfma<NKT>(zero16, st, 0, hb, lane);
-        acc[t] = tile_mfma<1>(v, st, NKT, &dout, lane);
-        ws.flip();
-    }
-    {
-        const char* msk = a.act + nk_act_offset(p, 2 + D - 1, a.G);
-        char* dst = a.dz + nk_dz_offset(p, 3, a.G);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            mask_to_frags(acc[t], msk, true, grp, NOW, t, c, h, hb[2 * t], hb[2 * t + 1]);
-            save_tile(dst, grp, NOW, t, c, h, hb[2 * t], hb[2 * t + 1]);
-        }
-    }
-    // ---- trunk L = D-1 .. 1: dH_{L-1} = W_L^T dZ_L -> dZ_{L-1} ------------------------------
-    for (int L = D - 1; L >= 1; --L) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            ws.issue((t + 1 < NT || L > 1) ? NKT : 0);
-            acc[t] = tile_mfma<NKT>(zero16, ws.stage(), 0, hb, lane);
-            ws.flip();
-        }
-        const char* msk = a.act + nk_act_offset(p, 2 + L - 1, a.G);
-        char* dst = a.dz + nk_dz_offset(p, 3 + D - L, a.G);
-        const bool relu = (L - 1 >= 1) || p.relu_first != 0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            mask_to_frags(acc[t], msk, relu, grp, NOW, t, c, h, hb[2 * t], hb[2 * t + 1]);
-            save_tile(dst, grp, NOW, t, c, h, hb[2 * t], hb[2 * t + 1]);
-        }
-    }
-}
 
 // --------------------------------------------------------------------------------------------
 // dW GEMM: C[m, n] += sum_p A[p, m] * B[p, n]  (A = dZ region, B = saved layer-input region)
@@ -359,9 +233,15 @@ extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const vo
     a.act = (const char*)act_save; a.d_raw = d_raw; a.dz = (char*)dz_scratch;
     a.P = R * (int64_t)n; a.G = nk_groups(a.P);
     hipStream_t st = nk_stream(stream);
-    const dim3 grid((unsigned)(a.G / 8)), block(512);
-    if (p.W == 256) hipLaunchKernelGGL((k_mlp_bwd<256, 128>), grid, block, 2 * (16 + 1) * 1024, st, a);
-    else hipLaunchKernelGGL((k_mlp_bwd<128, 64>), grid, block, 2 * (8 + 1) * 1024, st, a);
+    const int nw = nk_waves_per_wg();
+    const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
+    if (p.W == 256) {
+        if (nw == 8) hipLaunchKernelGGL((k_mlp_bwd<256, 128, 8>), grid, block, 2 * (16 + 1) * 1024, st, a);
+        else hipLaunchKernelGGL((k_mlp_bwd<256, 128, 4>), grid, block, 2 * (16 + 1) * 1024, st, a);
+    } else {
+        if (nw == 8) hipLaunchKernelGGL((k_mlp_bwd<128, 64, 8>), grid, block, 2 * (8 + 1) * 1024, st, a);
+        else hipLaunchKernelGGL((k_mlp_bwd<128, 64, 4>), grid, block, 2 * (8 + 1) * 1024, st, a);
+    }
     NK_CHECK_LAUNCH("k_mlp_bwd");
 
     // weight / bias gradients, one GEMM per (dZ, layer input) pair

@@ -128,154 +128,15 @@ struct FwdArgs {
     int n;                 // samples per ray
 };
 
-template <int W, int WD>
-__global__ __launch_bounds__(512, 2) void k_mlp_fwd(FwdArgs a) {
-    constexpr int NT = W / 32, NKT = W / 16, NTD = WD / 32, NKD = WD / 16;
-    constexpr int HALF = (NKT + 4 + 1) * 1024;          // largest stage: skip layer
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const NkPlan& p = a.plan;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const int64_t grp = (int64_t)blockIdx.x * 8 + wave;
-    const int64_t pt = grp * 32 + c;
-    const bool valid = pt < a.P;
-    const int64_t ptc = valid ? pt : a.P - 1;
-    const int64_t ray = ptc / a.n;
-    const float* rb = a.rays + ray * 11;
-    const float zv = a.z[ptc];
-    const float px = rb[0] + rb[3] * zv, py = rb[1] + rb[4] * zv, pz = rb[2] + rb[5] * zv;
-    const float vx = rb[8], vy = rb[9], vz = rb[10];
-    const int D = p.D;
-    const int NOW = W / 8;
+#include "nk_fwd_chain.inc"
 
-    WStream ws;
-    ws.g = a.packed; ws.ring = lds; ws.half_bytes = HALF; ws.cur = 1; ws.wave = wave; ws.lane = lane;
-    ws.issue(4 + 1);     // stage 0 = tile 0 of trunk layer 0 -> half 0
-    ws.flip();
-
-    f32x16 acc[NT];
-    Frag hb[2 * NT];
-
-    // ---- trunk layer 0: gamma(x) -> W ----------------------------------------------------
-    {
-        Frag pex[4];
-        pe_xyz_frags(px, py, pz, h, pex);
-        if (a.act) {
-            char* dst = a.act + nk_act_offset(p, 0, a.G);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) *(u32x4*)(dst + ((grp * 8 + 2 * s + h) * 32 + c) * 16) = pex[s].u;
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            // next stage: another tile of this layer, or the first tile of layer 1
-            const int next_nb = (t + 1 < NT) ? 5 : ((p.skip == 0 ? NKT + 4 : NKT) + 1);
-            ws.issue(next_nb);
-            const char* st = ws.stage();
-            acc[t] = tile_mfma<4>(lds_bias(st, 4, h), st, 0, pex, lane);
-            ws.flip();
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc_to_frags(acc[t], p.relu_first != 0, hb[2 * t], hb[2 * t + 1]);
-            if (a.act) save_tile(a.act + nk_act_offset(p, 2, a.G), grp, NOW, t, c, h, hb[2 * t], hb[2 * t + 1]);
-        }
-    }
-    // ---- trunk layers 1..D-1 -------------------------------------------------------------
-    for (int L = 1; L < D; ++L) {
-        const bool is_skip = (p.skip >= 0 && L == p.skip + 1);
-        const int nk_next_layer = (L + 1 < D) ? (((p.skip >= 0 && L + 1 == p.skip + 1) ? NKT + 4 : NKT) + 1) : (NKT + 1);  // next trunk layer or ALPHA
-        if (is_skip) {
-            Frag pex[4];
-            pe_xyz_frags(px, py, pz, h, pex);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                ws.issue((t + 1 < NT) ? NKT + 4 + 1 : nk_next_layer);
-                const char* st = ws.stage();
-                f32x16 v = tile_mfma<4>(lds_bias(st, NKT + 4, h), st, 0, pex, lane);
-                acc[t] = tile_mfma<NKT>(v, st, 4, hb, lane);
-                ws.flip();
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                ws.issue((t + 1 < NT) ? NKT + 1 : nk_next_layer);
-                const char* st = ws.stage();
-                acc[t] = tile_mfma<NKT>(lds_bias(st, NKT, h), st, 0, hb, lane);
-                ws.flip();
-            }
-        }
-        char* dst = a.act ? a.act + nk_act_offset(p, 2 + L, a.G) : nullptr;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc_to_frags(acc[t], true, hb[2 * t], hb[2 * t + 1]);
-            if (dst) save_tile(dst, grp, NOW, t, c, h, hb[2 * t], hb[2 * t + 1]);
-        }
-    }
-    // ---- ALPHA: 1 tile, row 0 = sigma_raw ------------------------------------------------
-    float sigma;
-    {
-        ws.issue(NKT + 1);                     // first FEAT tile
-        const char* st = ws.stage();
-        const f32x16 v = tile_mfma<NKT>(lds_bias(st, NKT, h), st, 0, hb, lane);
-        sigma = v[0];
-        ws.flip();
-    }
-    // ---- FEAT ----------------------------------------------------------------------------
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        ws.issue((t + 1 < NT) ? NKT + 1 : NKT + 2 + 1);   // next: FEAT tile or first VIEWS tile
-        const char* st = ws.stage();
-        acc[t] = tile_mfma<NKT>(lds_bias(st, NKT, h), st, 0, hb, lane);
-        ws.flip();
-    }
-    {
-        char* dst = a.act ? a.act + nk_act_offset(p, 2 + D, a.G) : nullptr;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc_to_frags(acc[t], p.relu_feat != 0, hb[2 * t], hb[2 * t + 1]);
-            if (dst) save_tile(dst, grp, NOW, t, c, h, hb[2 * t], hb[2 * t + 1]);
-        }
-    }
-    // ---- VIEWS: cat[feat, gamma(d)] -> WD, ReLU -------------------------------------------
-    Frag gb[2 * NTD];
-    {
-        Frag ped[2];
-        pe_dir_frags(vx, vy, vz, h, ped);
-        if (a.act) {
-            char* dst = a.act + nk_act_offset(p, 1, a.G);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) *(u32x4*)(dst + ((grp * 4 + 2 * s + h) * 32 + c) * 16) = ped[s].u;
-        }
-#pragma unroll
-        for (int t = 0; t < NTD; ++t) {
-            ws.issue((t + 1 < NTD) ? NKT + 2 + 1 : NKD + 1);   // next: VIEWS tile or the RGB tile
-            const char* st = ws.stage();
-            f32x16 v = tile_mfma<NKT>(lds_bias(st, NKT + 2, h), st, 0, hb, lane);
-            acc[t] = tile_mfma<2>(v, st, NKT, ped, lane);
-            ws.flip();
-        }
-        char* dst = a.act ? a.act + nk_act_offset(p, 3 + D, a.G) : nullptr;
-#pragma unroll
-        for (int t = 0; t < NTD; ++t) {
-            acc_to_frags(acc[t], true, gb[2 * t], gb[2 * t + 1]);
-            if (dst) save_tile(dst, grp, WD / 8, t, c, h, gb[2 * t], gb[2 * t + 1]);
-        }
-    }
-    // ---- RGB: 1 tile, rows 0..2 ------------------------------------------------------------
-    {
-        const char* st = ws.stage();
-        const f32x16 v = tile_mfma<NKD>(lds_bias(st, NKD, h), st, 0, gb, lane);
-        if (valid && h == 0) *(float4*)(a.raw + pt * 4) = make_float4(v[0], v[1], v[2], sigma);
-    }
-}
 
 extern "C" int64_t nk_act_bytes(const nk_arch* arch, int64_t R, int32_t n) {
     NkPlan p;
     int rc = nk_build_plan(arch, &p);
     if (rc < 0) return rc;
     if (R <= 0 || n <= 0) { nk_set_error("nk_act_bytes: non-positive size"); return NK_ERR_ARG; }
-    return nk_act_offset(p, nk_act_count(p), nk_groups(R * (int64_t)n));
+    return nk_mask_offset(p, nk_mask_count(p), nk_groups(R * (int64_t)n));
 }
 
 extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const float* ray_batch, const float* z,
@@ -289,14 +150,20 @@ extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const flo
     if (rc < 0) return rc;
     a.packed = (const char*)packed; a.rays = ray_batch; a.z = z; a.raw = raw; a.act = (char*)act_save;
     a.P = R * (int64_t)n; a.G = nk_groups(a.P); a.n = n;
-    const dim3 grid((unsigned)(a.G / 8)), block(512);
+    const int nw = nk_waves_per_wg();
+    const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
+    const bool save = act_save != nullptr;
+#define NK_FWD_LAUNCH(W_, WD_, NW_, LDS_) do { \
+        if (save) hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, true>), grid, block, LDS_, nk_stream(stream), a); \
+        else hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, false>), grid, block, LDS_, nk_stream(stream), a); } while (0)
     if (a.plan.W == 256) {
         constexpr int lds_bytes = 2 * (16 + 4 + 1) * 1024;
-        hipLaunchKernelGGL((k_mlp_fwd<256, 128>), grid, block, lds_bytes, nk_stream(stream), a);
+        if (nw == 8) NK_FWD_LAUNCH(256, 128, 8, lds_bytes); else NK_FWD_LAUNCH(256, 128, 4, lds_bytes);
     } else {
         constexpr int lds_bytes = 2 * (8 + 4 + 1) * 1024;
-        hipLaunchKernelGGL((k_mlp_fwd<128, 64>), grid, block, lds_bytes, nk_stream(stream), a);
+        if (nw == 8) NK_FWD_LAUNCH(128, 64, 8, lds_bytes); else NK_FWD_LAUNCH(128, 64, 4, lds_bytes);
     }
+#undef NK_FWD_LAUNCH
     NK_CHECK_LAUNCH("k_mlp_fwd");
     return NK_OK;
 }

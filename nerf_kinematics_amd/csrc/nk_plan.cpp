@@ -4,6 +4,7 @@
 // /root/reference/trained_models/nerf-pytorch/lego-lowres3/checkpoint110000.ckpt for FLEXIBLE).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "nk_common.h"
 
@@ -14,6 +15,15 @@ void nk_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int nk_waves_per_wg() {
+    static int nw = 0;
+    if (nw == 0) {
+        const char* e = getenv("NK_WAVES");
+        nw = (e && atoi(e) == 8) ? 8 : 4;
+    }
+    return nw;
 }
 
 extern "C" const char* nk_last_error(void) { return g_err; }

@@ -63,8 +63,9 @@ def test_workspace_sizes_scale_with_rays():
     tr1 = L.nk_render_workspace_bytes(a, a, o, 1024, 1)
     tr2 = L.nk_render_workspace_bytes(a, a, o, 2048, 1)
     assert 0 < inf1 < tr1 < tr2 and abs(tr2 / tr1 - 2) < 0.01
-    # activations: 2528 bf16 per point-evaluation for the 8x256 network
-    assert L.nk_act_bytes(a, 1024, 192) == 1024 * 192 * 2528 * 2
+    # activations: 2528 bf16 per point-evaluation for the 8x256 network, plus one ReLU-mask bit per
+    # hidden activation (10 layers x 16 bytes per lane = 32 bytes per point and layer)
+    assert L.nk_act_bytes(a, 1024, 192) == 1024 * 192 * (2528 * 2 + 10 * 32)
     assert L.nk_render_workspace_bytes(a, None, o, 1024, 0) == -1      # fine samples without a fine network
 
 
