@@ -45,28 +45,8 @@ def parse():
     ap.add_argument("--views", type=int, default=4, help="teacher views rendered for the synthetic dataset")
     ap.add_argument("--res", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=192, help="rays in the CPU baseline sample")
+    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays in the CPU baseline sample")
     return ap.parse_args()
-
-
-def teacher_views(nk, O, dev, n_views, res, rank):
-    """Render the synthetic dataset: the trained lego checkpoint seen from a ring of poses."""
-    w = np.load(os.path.join(ROOT, "tests", "golden", "lego_lowres3_weights.npz"))
-    c = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(w["coarse"]).to(dev))
-    f = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(w["fine"]).to(dev))
-    focal = 0.5 * res / math.tan(0.5 * 0.6911112070083618)
-    imgs, poses = [], []
-    for k in range(n_views):
-        theta = 360.0 * (k + 0.37 * rank) / n_views
-        phi = -30.0 + 15.0 * math.sin(2 * math.pi * k / max(n_views, 1))
-        c2w = O.spherical_pose(theta, phi, 4.0)
-        rb = nk.get_rays(res, res, focal, c2w, near=2.0, far=6.0, device=dev)
-        with torch.no_grad():
-            parts = [nk.render_rays(rb[s:s + 65536], c, f, num_coarse=64, num_fine=128)[0]
-                     for s in range(0, rb.shape[0], 65536)]
-        imgs.append(torch.cat(parts).clamp(0, 1))
-        poses.append(c2w)
-    return imgs, poses, focal
 
 
 def cpu_baseline(O, rays, seed=0):
@@ -109,23 +89,21 @@ def main():
 
     import nerf_kinematics_amd as nk
     from nerf_kinematics_amd.trainer import Trainer, TrainOpts
-    from oracle import nerf_oracle as O        # cpu_baseline leg + pose helper only
 
-    imgs, poses, focal = teacher_views(nk, O, dev, a.views, a.res, rank)
+    from nerf_kinematics_amd.datasets import RaySampler, teacher_scene
+    # the synthetic photographs: the trained lego checkpoint seen from a ring of poses (8-bit, in HBM)
+    scene = teacher_scene(os.path.join(ROOT, "tests", "golden", "lego_lowres3_weights.npz"), a.views, 0, a.res, dev,
+                          phase=0.37 * rank)
     opts = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=a.rays, perturb=True,
                      radiance_field_noise_std=0.2, lr=5e-4, seed=42)
     tr = Trainer(nk.ARCH_RUN_NERF, nk.ARCH_RUN_NERF, opts, dev, rays_per_step=a.rays)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    npix = a.res * a.res
+    sampler = RaySampler(scene, a.rays, seed=1234, rank=rank, world=world)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     dummy = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     def one_step(i, events):
-        v = i % len(imgs)
-        pix = torch.randint(0, npix, (a.rays,), generator=gen, device=dev, dtype=torch.int32)
-        rb = nk.get_rays(a.res, a.res, focal, poses[v], near=2.0, far=6.0, pixels=pix)
-        target = imgs[v][pix.long()]
+        rb, target = sampler.next(i)        # one kernel: pixel draw + get_rays + target colours
         return tr.step(rb, target, events=events)
 
     for i in range(a.warmup):
@@ -168,6 +146,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+            from oracle import nerf_oracle as O        # the CPU restatement is only ever the baseline leg
             v, t = cpu_baseline(O, a.cpu_rays)
             res["cpu_baseline"] = {"value": v, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
                                    "kind": "port",

@@ -103,6 +103,14 @@ int nk_pack_weights(const nk_arch* arch, const float* params, void* packed, void
  * pixel_idx: R flat pixel indices (row*W+col) or NULL for pixels first_pixel..first_pixel+R-1 */
 int nk_get_rays(const nk_camera* cam /*host*/, const int32_t* pixel_idx, int64_t first_pixel,
                 int64_t R, float* ray_batch, void* stream);
+/* Ray selection of one training iteration on one view (the train loop's random pixel choice,
+ * get_rays and target gather; config.yml:51 num_random_rays): R pixels drawn with replacement
+ * from RNG stream 4 at element `counter` + r, their ray-batch rows, and their colours from the
+ * 8-bit H x W x channels image (channels 3 | 4; with 4 and white_background the colour is
+ * composited onto white, otherwise alpha is ignored).  pixel_idx (optional) receives the draw. */
+int nk_sample_training_rays(const nk_camera* cam /*host*/, const uint8_t* image, int32_t channels,
+                            int32_t white_background, uint32_t seed, uint64_t counter, int64_t R,
+                            float* ray_batch, float* target, int32_t* pixel_idx, void* stream);
 /* Coarse depths: linspace in depth or disparity + stratified jitter (render_rays, first part) */
 int nk_stratified_z(const float* ray_batch, int64_t R, const nk_render_opts* opts, float* z,
                     void* stream);

@@ -9,12 +9,7 @@
 // ============================================================================================
 struct CamArgs { nk_camera cam; };
 
-__global__ void k_get_rays(CamArgs a, const int32_t* __restrict__ pixel_idx, int64_t first_pixel,
-                           int64_t R, float* __restrict__ rb) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    const nk_camera& cam = a.cam;
-    const int64_t pix = pixel_idx ? (int64_t)pixel_idx[r] : first_pixel + r;
+NK_D void ray_row(const nk_camera& cam, int64_t pix, float* __restrict__ out) {
     const float i = (float)(pix % cam.W), j = (float)(pix / cam.W);
     const float dx = (i - cam.cx) / cam.fx, dy = -(j - cam.cy) / cam.fy, dz = -1.0f;
     const float* m = cam.c2w;
@@ -35,11 +30,38 @@ __global__ void k_get_rays(CamArgs a, const int32_t* __restrict__ pixel_idx, int
         const float d2 = -2.0f * cam.ndc_near / o[2];
         o[0] = o0; o[1] = o1; o[2] = o2; d[0] = d0; d[1] = d1; d[2] = d2;
     }
-    float* out = rb + r * 11;
     out[0] = o[0]; out[1] = o[1]; out[2] = o[2];
     out[3] = d[0]; out[4] = d[1]; out[5] = d[2];
     out[6] = cam.near; out[7] = cam.far;
     out[8] = v[0]; out[9] = v[1]; out[10] = v[2];
+}
+
+__global__ void k_get_rays(CamArgs a, const int32_t* __restrict__ pixel_idx, int64_t first_pixel,
+                           int64_t R, float* __restrict__ rb) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    ray_row(a.cam, pixel_idx ? (int64_t)pixel_idx[r] : first_pixel + r, rb + r * 11);
+}
+
+// Training batch of one view: R pixels drawn with replacement (pixel of ray r = floor(u32 * H*W /
+// 2^32) with u32 = element counter + r of RNG stream NK_STREAM_PIXELS), their rays, and their
+// colours from the 8-bit image (alpha composited onto white when asked, otherwise rgb as stored).
+__global__ void k_sample_training_rays(CamArgs a, const uint8_t* __restrict__ image, int channels, int white,
+                                       uint32_t seed, uint64_t counter, int64_t R, float* __restrict__ rb,
+                                       float* __restrict__ target, int32_t* __restrict__ pixel_idx) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const uint64_t npix = (uint64_t)a.cam.H * (uint64_t)a.cam.W;
+    const int64_t pix = (int64_t)(((uint64_t)nk_rand_u32(seed, NK_STREAM_PIXELS, counter + (uint64_t)r) * npix) >> 32);
+    ray_row(a.cam, pix, rb + r * 11);
+    const uint8_t* px = image + pix * channels;
+    float c[3] = {(float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f};
+    if (channels == 4 && white) {
+        const float al = (float)px[3] / 255.0f;
+        for (int k = 0; k < 3; ++k) c[k] = __fadd_rn(__fmul_rn(c[k], al), 1.0f - al);
+    }
+    target[r * 3 + 0] = c[0]; target[r * 3 + 1] = c[1]; target[r * 3 + 2] = c[2];
+    if (pixel_idx) pixel_idx[r] = (int32_t)pix;
 }
 
 extern "C" int nk_get_rays(const nk_camera* cam, const int32_t* pixel_idx, int64_t first_pixel,
@@ -53,6 +75,22 @@ extern "C" int nk_get_rays(const nk_camera* cam, const int32_t* pixel_idx, int64
     hipLaunchKernelGGL(k_get_rays, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, nk_stream(stream),
                        a, pixel_idx, first_pixel, R, ray_batch);
     NK_CHECK_LAUNCH("k_get_rays");
+    return NK_OK;
+}
+
+extern "C" int nk_sample_training_rays(const nk_camera* cam, const uint8_t* image, int32_t channels,
+                                       int32_t white_background, uint32_t seed, uint64_t counter, int64_t R,
+                                       float* ray_batch, float* target, int32_t* pixel_idx, void* stream) {
+    if (!cam || !image || !ray_batch || !target || R <= 0)
+        NK_FAIL(NK_ERR_ARG, "nk_sample_training_rays: null pointer or R <= 0");
+    if (cam->H <= 0 || cam->W <= 0 || cam->fx == 0.0f || cam->fy == 0.0f)
+        NK_FAIL(NK_ERR_ARG, "nk_sample_training_rays: bad camera (H=%d W=%d fx=%g fy=%g)", cam->H, cam->W, cam->fx, cam->fy);
+    if (channels != 3 && channels != 4)
+        NK_FAIL(NK_ERR_ARG, "nk_sample_training_rays: %d channels (3 or 4)", channels);
+    CamArgs a; a.cam = *cam;
+    hipLaunchKernelGGL(k_sample_training_rays, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, nk_stream(stream),
+                       a, image, channels, white_background, seed, counter, R, ray_batch, target, pixel_idx);
+    NK_CHECK_LAUNCH("k_sample_training_rays");
     return NK_OK;
 }
 

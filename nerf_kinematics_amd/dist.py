@@ -46,3 +46,8 @@ def params_in_sync(flat: torch.Tensor, group=None) -> bool:
     dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
     return bool(torch.equal(lo, hi))
+
+
+def shutdown() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

@@ -49,6 +49,7 @@ SIGNATURES = {
     "nk_packed_bytes": (_I64, [_PA]),
     "nk_pack_weights": (C.c_int, [_PA, _P, _P, _P]),
     "nk_get_rays": (C.c_int, [_PC, _P, _I64, _I64, _P, _P]),
+    "nk_sample_training_rays": (C.c_int, [_PC, _P, _I32, _I32, C.c_uint32, C.c_uint64, _I64, _P, _P, _P, _P]),
     "nk_stratified_z": (C.c_int, [_P, _I64, _PO, _P, _P]),
     "nk_act_bytes": (_I64, [_PA, _I64, _I32]),
     "nk_mlp_forward": (C.c_int, [_PA, _P, _P, _P, _I64, _I32, _P, _P, _P]),

@@ -85,7 +85,8 @@ class Trainer:
         self.coarse = NeRFModel(arch_coarse, self.params[:nc])
         self.fine = NeRFModel(arch_fine, self.params[nc_pad:]) if use_fine else None
         self._nc, self._nc_pad = nc, nc_pad
-        self.iteration = 0
+        self.iteration = 0          # training iterations done (drives the learning-rate decay and the RNG)
+        self.opt_steps = 0          # optimiser steps done (Adam bias correction; survives resume)
         self._alloc(self.R)
 
     # -- buffers ----------------------------------------------------------------------------
@@ -190,8 +191,9 @@ class Trainer:
             if self.world > 1:
                 torch.distributed.all_reduce(self.grad, group=self.pg)   # one flat buffer, both networks
             self.iteration += 1
+            self.opt_steps += 1
             _lib.check(L.nk_adam_step(self.params.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
-                                      self.exp_avg_sq.data_ptr(), self.params.numel(), self.iteration,
+                                      self.exp_avg_sq.data_ptr(), self.params.numel(), self.opt_steps,
                                       lr_at(self.iteration - 1, self.opts), self.opts.betas[0], self.opts.betas[1],
                                       self.opts.eps, 1.0 / self.world, st))
             self.coarse.pack()
@@ -201,6 +203,41 @@ class Trainer:
 
     def _rank(self) -> int:
         return torch.distributed.get_rank(self.pg) if self.world > 1 else 0
+
+    # -- checkpoints ----------------------------------------------------------------------------
+    def export_state(self, loss: float = float("nan"), psnr: float = float("nan")):
+        """Everything a reference-layout checkpoint carries, copied to the CPU.  ``iter`` is the index
+        of the last completed iteration, as in the reference's files (its checkpoint110000 holds
+        Adam step counts of 110001 and more)."""
+        from .checkpoint import TrainState
+        nc, ncp = self._nc, self._nc_pad
+        cpu = lambda t: t.detach().to("cpu", copy=True)
+        fine = self.fine is not None
+        cut = lambda t: [cpu(t[:nc])] + ([cpu(t[ncp:])] if fine else [])
+        return TrainState(iteration=self.iteration - 1, coarse=cpu(self.params[:nc]),
+                          fine=cpu(self.params[ncp:]) if fine else None, exp_avg=cut(self.exp_avg),
+                          exp_avg_sq=cut(self.exp_avg_sq), opt_step=self.opt_steps,
+                          lr=lr_at(max(self.iteration - 1, 0), self.opts), loss=loss, psnr=psnr)
+
+    def import_state(self, s) -> None:
+        """Resume from a TrainState (parameters, Adam moments); training continues with the iteration
+        after the stored one."""
+        nc, ncp = self._nc, self._nc_pad
+        if s.coarse.numel() != nc or ((s.fine is not None) != (self.fine is not None)):
+            raise ValueError("checkpoint networks do not match the trainer's")
+        self.params[:nc] = s.coarse.to(self.device)
+        if self.fine is not None:
+            self.params[ncp:] = s.fine.to(self.device)
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        if s.exp_avg:
+            self.exp_avg[:nc] = s.exp_avg[0].to(self.device); self.exp_avg_sq[:nc] = s.exp_avg_sq[0].to(self.device)
+            if self.fine is not None:
+                self.exp_avg[ncp:] = s.exp_avg[1].to(self.device); self.exp_avg_sq[ncp:] = s.exp_avg_sq[1].to(self.device)
+        self.iteration = int(s.iteration) + 1
+        self.opt_steps = int(s.opt_step) if s.exp_avg else 0
+        self.coarse.pack()
+        if self.fine is not None:
+            self.fine.pack()
 
     # -- inference --------------------------------------------------------------------------
     @torch.no_grad()

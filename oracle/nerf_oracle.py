@@ -500,3 +500,20 @@ def spherical_pose(theta_deg: float, phi_deg: float, radius: float) -> torch.Ten
     c2w = rot_theta(theta_deg / 180.0 * math.pi) @ c2w
     flip = torch.tensor([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=torch.float64)
     return (flip @ c2w).to(torch.float32)
+
+
+def sample_training_rays(H: int, W: int, focal: float, c2w: torch.Tensor, image_u8: np.ndarray, white: bool,
+                         near: float, far: float, seed: int, counter: int, R: int):
+    """Ray selection of one training iteration on one view: pixel of ray r = floor(u32 * H*W / 2^32)
+    with u32 = element counter + r of RNG stream STREAM_PIXELS (drawn with replacement, like the
+    train loop's random pixel choice); returns (pixel indices, ray batch [R, 11], target [R, 3])."""
+    draws = rand_u32(seed, STREAM_PIXELS, np.arange(R, dtype=np.uint64) + np.uint64(counter)).astype(np.uint64)
+    pix = ((draws * np.uint64(H * W)) >> np.uint64(32)).astype(np.int64)
+    ro, rd = get_rays(H, W, focal, c2w)
+    rb = make_ray_batch(ro, rd, near, far)[torch.from_numpy(pix)]
+    px = torch.from_numpy(np.asarray(image_u8).reshape(H * W, -1)[pix].astype(np.float32)) / 255.0
+    if px.shape[1] == 4 and white:
+        target = px[:, :3] * px[:, 3:] + (1.0 - px[:, 3:])
+    else:
+        target = px[:, :3]
+    return pix, rb, target.contiguous()

@@ -40,6 +40,28 @@ def dump_ckpt(name, arch, out_name):
     return coarse, fine
 
 
+def dump_layout(name, out_name):
+    """Structure of a reference checkpoint (keys, shapes, dtypes, optimiser bookkeeping): what a
+    writer has to reproduce for the file to load back into upstream code."""
+    ck = torch.load(f"{REF}/trained_models/nerf-pytorch/{name}/checkpoint110000.ckpt",
+                    weights_only=True, map_location="cpu")
+    desc = lambda t: [list(t.shape), str(t.dtype)]
+    og = ck["optimizer_state_dict"]
+    layout = {
+        "top_level": {k: type(v).__name__ for k, v in ck.items()},
+        "iter": int(ck["iter"]), "psnr": float(ck["psnr"]), "loss": desc(ck["loss"]),
+        "model_coarse_state_dict": {k: desc(v) for k, v in ck["model_coarse_state_dict"].items()},
+        "model_fine_state_dict": {k: desc(v) for k, v in ck["model_fine_state_dict"].items()},
+        "optimizer_state": {str(i): {k: desc(v) for k, v in e.items()} for i, e in og["state"].items()},
+        "optimizer_step": float(og["state"][0]["step"]),
+        "param_groups": [{k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in g.items()}
+                         for g in og["param_groups"]],
+    }
+    with open(os.path.join(GOLD, out_name), "w") as fh:
+        json.dump(layout, fh, indent=1)
+    print(out_name)
+
+
 def probe_rays(H=100, W=100):
     focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
     c2w = O.spherical_pose(45.0, -30.0, 4.0)
@@ -52,6 +74,8 @@ def main():
     torch.manual_seed(0)
     coarse, fine = dump_ckpt("lego-lowres3", O.ARCH_LEGO_CKPT, "lego_lowres3_weights.npz")
     dump_ckpt("wheel_robot6", O.ARCH_WHEEL_CKPT, "wheel_robot6_weights.npz")
+    dump_layout("lego-lowres3", "lego_ckpt_layout.json")
+    dump_layout("wheel_robot6", "wheel_ckpt_layout.json")
 
     # ---- probe render (oracle pin) ----------------------------------------------------------
     net_c = O.NeRFNet.from_flat(O.ARCH_LEGO_CKPT, torch.from_numpy(coarse))
