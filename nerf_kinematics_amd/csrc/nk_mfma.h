@@ -144,6 +144,26 @@ NK_D f32x16 tile_run(f32x16 acc, const char* stage, int lane, const Frag* b0, co
     return acc;
 }
 
+// Streaming stores for saved activations / dZ: written once, read once by a later kernel, and at
+// 5 KB per point they would otherwise push the weight stream out of L2.
+#ifndef NK_NT_STORES
+#define NK_NT_STORES 1
+#endif
+NK_D void st_nt(u32x2* p, u32x2 v) {
+#if NK_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+NK_D void st_nt(u32x4* p, u32x4 v) {
+#if NK_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // Pin two fragments: everything that computes them is emitted before this point (keeps the
 // mask / convert of a finished tile ahead of the next stream load instead of being sunk below it).
 NK_D void pin_frags(Frag& f0, Frag& f1) {
@@ -154,10 +174,10 @@ NK_D void pin_frags(Frag& f0, Frag& f1) {
 NK_D void save_tile(char* dst, int64_t grp, int NO, int t, int c, int h, const Frag& f0, const Frag& f1) {
     // features 8q+4h+{0..3} of tile t are dwords (2q&3.., ) of fragment q>>1
     char* base = dst + ((grp * NO + 4 * t) * 32 + c) * 16 + 8 * h;
-    *(u32x2*)(base + 0 * 512) = u32x2{f0.u[0], f0.u[1]};
-    *(u32x2*)(base + 1 * 512) = u32x2{f0.u[2], f0.u[3]};
-    *(u32x2*)(base + 2 * 512) = u32x2{f1.u[0], f1.u[1]};
-    *(u32x2*)(base + 3 * 512) = u32x2{f1.u[2], f1.u[3]};
+    st_nt((u32x2*)(base + 0 * 512), u32x2{f0.u[0], f0.u[1]});
+    st_nt((u32x2*)(base + 1 * 512), u32x2{f0.u[2], f0.u[3]});
+    st_nt((u32x2*)(base + 2 * 512), u32x2{f1.u[0], f1.u[1]});
+    st_nt((u32x2*)(base + 3 * 512), u32x2{f1.u[2], f1.u[3]});
 }
 
 NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1);

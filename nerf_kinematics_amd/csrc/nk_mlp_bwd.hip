@@ -33,7 +33,7 @@ struct GemmArgs {
     const char* A; const char* B;   // regions [G][MT*4][32][8], [G][NT*4][32][8] bf16
     int MT, NT;                     // 32-wide tiles of A features / B features
     int WM, WN;                     // wave grid (WM*WN <= 8); wave tile = (MT/WM) x (NT/WN) tiles
-    int64_t n_stages;               // G / 2 (a stage = 2 groups = 64 points)
+    int64_t n_stages;               // G (a stage = 1 group = 32 points)
     int64_t stages_per_wg;
     float* grad;                    // flat gradient
     int w_off, ld;                  // destination matrix origin and leading dimension
@@ -42,50 +42,77 @@ struct GemmArgs {
     int b_off;                      // bias gradient origin, or -1
 };
 
-NK_D bf16x8 tr_frag(const char* piece, int tile, int ks, int lane) {
-    // MFMA operand whose 32 "rows" are features 32*tile.. and whose k index is the point
+// Transposed LDS reads are issued from inline asm: hipcc drains vmcnt before a
+// ds_read_b64_tr_b16 INTRINSIC that follows an LDS-DMA load (it does not for plain LDS loads),
+// which would serialise every stage's loads with its MFMAs.  The price is that the waits for the
+// read results are written by hand too (tr_wait).
+struct TrFrag { u32x2 lo, hi; };
+
+// issue the two 8-byte transposed reads of one MFMA operand: 32 "rows" = features 32*tile..,
+// k index = point 16*ks..; `piece` is the LDS byte address of the [octet][point][8] image
+NK_D void tr_issue(TrFrag& f, uint32_t piece, int tile, int ks, int lane) {
     const int g4 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const int o = 4 * tile + 2 * (g4 & 1) + (pp >> 1);
     const int sw = (o & 3) << 2;
     const int c0 = 16 * ks + 8 * (g4 >> 1) + q;
-    const char* base = piece + o * 512 + (pp & 1) * 8;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NK_LDS bf16x4*)(base + ((c0) ^ sw) * 16));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NK_LDS bf16x4*)(base + ((c0 + 4) ^ sw) * 16));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
+    const uint32_t base = piece + o * 512 + (pp & 1) * 8;
+    const uint32_t a0 = base + ((c0) ^ sw) * 16, a1 = base + ((c0 + 4) ^ sw) * 16;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a1));
+}
+template <int N>
+NK_D void tr_wait(TrFrag (&f)[N]) {           // results of every read issued so far have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i].lo), "+v"(f[i].hi));
+}
+NK_D bf16x8 tr_value(const TrFrag& f) {
+    const u32x4 u = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
+    return __builtin_bit_cast(bf16x8, u);
 }
 
-template <int TM, int TN>
-__global__ __launch_bounds__(512, 2) void k_dw_gemm(GemmArgs a) {
+// A stage is one group of 32 points: A piece (MT*2 KiB) then B piece (NT*2 KiB).  Stages go
+// through a ring of NK_GEMM_RING LDS slots with three stages in flight, because one CU needs
+// ~50 KB of loads outstanding at all times to keep its share of HBM bandwidth busy.  Order per
+// stage s: counted wait (stage s landed; the loads of s+1, s+2 stay in flight) -> barrier (also
+// retires every wave's reads of slot (s-1) % RING) -> issue stage s+3 into that slot -> MFMAs.
+enum { NK_GEMM_RING = 4 };
+
+template <int N>
+NK_D void gemm_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmArgs a) {
+    constexpr int TM = MT / WM, TN = NT / WN;       // wave tile, in 32x32 tiles
+    static_assert(TM * WM == MT && TN * WN == NT && WM * WN <= 8, "wave grid must tile the output");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int MT = a.MT, NT = a.NT;
-    const int grp_bytes = (MT + NT) * 2048;         // one group's A piece then B piece
-    const int stage_bytes = 2 * grp_bytes;
-    const int blocks_per_stage = 2 * (MT + NT) * 2;
-    const bool active = wave < a.WM * a.WN;
-    const int wm = active ? wave / a.WN : 0, wn = active ? wave % a.WN : 0;
+    constexpr int stage_bytes = (MT + NT) * 2048;       // one group's A piece then B piece
+    constexpr int blocks_per_stage = (MT + NT) * 2;
+    constexpr int min_pieces = blocks_per_stage / 8;    // every wave issues at least this many loads per stage
+    const bool active = wave < WM * WN;
+    const int wm = active ? wave / WN : 0, wn = active ? wave % WN : 0;
     const int64_t s0 = (int64_t)blockIdx.x * a.stages_per_wg;
     int64_t s1 = s0 + a.stages_per_wg;
     if (s1 > a.n_stages) s1 = a.n_stages;
     if (s0 >= s1) return;
 
-    auto issue = [&](int64_t stage, int half) {
-        char* dst = lds + half * stage_bytes;
-        for (int b = wave; b < blocks_per_stage; b += 8) {
-            const int gi = b / ((MT + NT) * 2);               // group inside the stage
-            const int rel = b - gi * (MT + NT) * 2;           // 1-KiB block inside the group's A|B image
-            const bool isA = rel < MT * 2;
-            const int pb = isA ? rel : rel - MT * 2;          // block inside the piece
-            const int64_t grp = stage * 2 + gi;
-            const char* src = isA ? a.A + grp * MT * 2048 : a.B + grp * NT * 2048;
+    auto issue = [&](int64_t stage) {
+        char* dst = lds + (int)(stage % NK_GEMM_RING) * stage_bytes;
+#pragma unroll
+        for (int i = 0; i < (blocks_per_stage + 7) / 8; ++i) {      // compile-time trip count: the compiler
+            const int b = wave + 8 * i;                             // would drain vmcnt after a real loop
+            if (b >= blocks_per_stage) break;
+            const bool isA = b < MT * 2;
+            const int pb = isA ? b : b - MT * 2;            // 1-KiB block inside the piece
+            const char* src = isA ? a.A + stage * MT * 2048 : a.B + stage * NT * 2048;
             const int o = 2 * pb + (lane >> 5), cpos = lane & 31;
             const int csrc = cpos ^ ((o & 3) << 2);           // swizzle on the source side
             __builtin_amdgcn_global_load_lds((const NK_GLB void*)(src + (o * 32 + csrc) * 16),
-                                             (NK_LDS void*)(dst + gi * grp_bytes + rel * 1024), 16, 0, 0);
+                                             (NK_LDS void*)(dst + b * 1024), 16, 0, 0);
         }
     };
 
@@ -100,47 +127,55 @@ __global__ __launch_bounds__(512, 2) void k_dw_gemm(GemmArgs a) {
     bf16x2 ones; ones[0] = (__bf16)1.0f; ones[1] = (__bf16)1.0f;
     const bool want_bias = a.b_off >= 0;
 
-    issue(s0, 0);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    int cur = 0;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(NK_LDS char*)lds;
+    for (int64_t s = s0; s < s0 + 3 && s < s1; ++s) issue(s);
     for (int64_t s = s0; s < s1; ++s) {
-        if (s + 1 < s1) issue(s + 1, cur ^ 1);
+        // loads issued after stage s: those of the stages s+1, s+2 that exist
+        const int64_t left = s1 - 1 - s;
+        if (left >= 2) gemm_wait_barrier<2 * min_pieces>();
+        else if (left == 1) gemm_wait_barrier<min_pieces>();
+        else gemm_wait_barrier<0>();
+        if (s + 3 < s1) issue(s + 3);
         if (active) {
-            const char* st = lds + cur * stage_bytes;
+            const uint32_t pa = lds0 + (uint32_t)(s % NK_GEMM_RING) * stage_bytes;
+            const uint32_t pb = pa + MT * 2048;
+            TrFrag fa[2][TM], fb[2][TN];        // both k-steps of the stage: the second is read under the first's MFMAs
 #pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                const char* pa = st + gi * grp_bytes;
-                const char* pb = pa + MT * 2048;
+            for (int i = 0; i < TM; ++i) tr_issue(fa[0][i], pa, wm * TM + i, 0, lane);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 af[TM], bf[TN];
+            for (int j = 0; j < TN; ++j) tr_issue(fb[0][j], pb, wn * TN + j, 0, lane);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) af[i] = tr_frag(pa, wm * TM + i, ks, lane);
+            for (int ks = 0; ks < 2; ++ks) {
+                tr_wait(fa[ks]); tr_wait(fb[ks]);
+                if (ks == 0) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[j] = tr_frag(pb, wn * TN + j, ks, lane);
+                    for (int i = 0; i < TM; ++i) tr_issue(fa[1][i], pa, wm * TM + i, 1, lane);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                    for (int j = 0; j < TN; ++j) tr_issue(fb[1][j], pb, wn * TN + j, 1, lane);
+                }
+                bf16x8 af[TM], bf[TN];
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                    // bias gradient: the WN waves of a row share it, each takes its k-steps
-                    if (want_bias && ((2 * gi + ks) % a.WN) == wn) {
+                for (int i = 0; i < TM; ++i) af[i] = tr_value(fa[ks][i]);
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) {
+                for (int j = 0; j < TN; ++j) bf[j] = tr_value(fb[ks][j]);
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) {
-                                bf16x2 pr; pr[0] = af[i][2 * w]; pr[1] = af[i][2 * w + 1];
-                                bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
-                            }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                // bias gradient: the WN waves of a row share it, each takes its k-steps
+                if (want_bias && ((2 * (int)(s & 1) + ks) % WN) == wn) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            bf16x2 pr; pr[0] = af[i][2 * w]; pr[1] = af[i][2 * w + 1];
+                            bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
                         }
                     }
                 }
             }
         }
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        cur ^= 1;
     }
     if (!active) return;
     // epilogue: atomically add this K-slice's tiles into the flat gradient
@@ -182,30 +217,29 @@ static int launch_gemm(const NkPlan& p, const char* A, int MA, const char* B, in
                        int col_count, int nfreq, int b_off, hipStream_t stream) {
     GemmArgs g;
     g.A = A; g.B = B; g.MT = MA / 32; g.NT = NB / 32;
-    g.n_stages = G / 2;
-    g.stages_per_wg = (g.n_stages + 1023) / 1024;
+    g.n_stages = G;
+    static const int target_wgs = []() { const char* e = getenv("NK_GEMM_WGS"); const int v = e ? atoi(e) : 0;
+                                         return v > 0 ? v : 256; }();
+    g.stages_per_wg = (g.n_stages + target_wgs - 1) / target_wgs;
     if (g.stages_per_wg < 1) g.stages_per_wg = 1;
     g.grad = grad; g.w_off = w_off; g.ld = ld; g.row_first = row_first; g.row_count = row_count; g.row_dst0 = row_dst0;
     g.colmode = colmode; g.col_base = col_base; g.col_count = col_count; g.nfreq = nfreq; g.b_off = b_off;
     const unsigned nwg = (unsigned)((g.n_stages + g.stages_per_wg - 1) / g.stages_per_wg);
-    const int lds_bytes = 2 * 2 * (g.MT + g.NT) * 2048;
-    int TM, TN;
-    // wave tilings: (MT, NT) -> (TM, TN, WM, WN)
-    if (g.MT == 8 && g.NT == 8) { TM = 4; TN = 2; g.WM = 2; g.WN = 4; }
-    else if (g.MT == 8 && g.NT == 2) { TM = 2; TN = 1; g.WM = 4; g.WN = 2; }
-    else if (g.MT == 4 && g.NT == 8) { TM = 2; TN = 2; g.WM = 2; g.WN = 4; }
-    else if (g.MT == 4 && g.NT == 4) { TM = 2; TN = 1; g.WM = 2; g.WN = 4; }
-    else if (g.MT * g.NT <= 8) { TM = 1; TN = 1; g.WM = g.MT; g.WN = g.NT; }
-    else NK_FAIL(NK_ERR_UNSUPPORTED, "dW GEMM: no wave tiling for %d x %d tiles", g.MT, g.NT);
+    const int lds_bytes = NK_GEMM_RING * (g.MT + g.NT) * 2048;
     const dim3 grid(nwg), block(512);
-#define NK_GEMM_LAUNCH(A_, B_) do { \
-        NK_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_gemm<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
-        hipLaunchKernelGGL((k_dw_gemm<A_, B_>), grid, block, lds_bytes, stream, g); } while (0)
-    if (TM == 4 && TN == 2) NK_GEMM_LAUNCH(4, 2);
-    else if (TM == 2 && TN == 2) NK_GEMM_LAUNCH(2, 2);
-    else if (TM == 2 && TN == 1) NK_GEMM_LAUNCH(2, 1);
-    else NK_GEMM_LAUNCH(1, 1);
-#undef NK_GEMM_LAUNCH
+    // (A tiles, B tiles) -> wave grid; every shape the supported networks produce
+#define NK_GEMM_CASE(MT_, NT_, WM_, WN_) \
+    if (g.MT == MT_ && g.NT == NT_) { \
+        g.WM = WM_; g.WN = WN_; \
+        NK_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_gemm<MT_, NT_, WM_, WN_>, \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+        hipLaunchKernelGGL((k_dw_gemm<MT_, NT_, WM_, WN_>), grid, block, lds_bytes, stream, g); \
+    } else
+    NK_GEMM_CASE(8, 8, 2, 4) NK_GEMM_CASE(8, 2, 4, 2) NK_GEMM_CASE(4, 8, 2, 4) NK_GEMM_CASE(4, 4, 2, 4)
+    NK_GEMM_CASE(1, 4, 1, 4) NK_GEMM_CASE(1, 8, 1, 8) NK_GEMM_CASE(4, 1, 4, 1)
+    NK_GEMM_CASE(4, 2, 4, 2) NK_GEMM_CASE(2, 4, 2, 4) NK_GEMM_CASE(1, 2, 1, 2) NK_GEMM_CASE(2, 1, 2, 1)
+    NK_FAIL(NK_ERR_UNSUPPORTED, "dW GEMM: no kernel for %d x %d tiles", g.MT, g.NT);
+#undef NK_GEMM_CASE
     NK_CHECK_LAUNCH("k_dw_gemm");
     (void)p;
     return NK_OK;

@@ -126,6 +126,9 @@ struct FwdArgs {
     char* act;             // saved activations or null
     int64_t P, G;
     int n;                 // samples per ray
+#ifdef NK_STAMPS
+    long long* stamps;     // debug build: per-wave cycle stamps of one workgroup
+#endif
 };
 
 #include "nk_fwd_chain.inc"
@@ -150,6 +153,9 @@ extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const flo
     if (rc < 0) return rc;
     a.packed = (const char*)packed; a.rays = ray_batch; a.z = z; a.raw = raw; a.act = (char*)act_save;
     a.P = R * (int64_t)n; a.G = nk_groups(a.P); a.n = n;
+#ifdef NK_STAMPS
+    { const char* e = getenv("NK_STAMP_PTR"); a.stamps = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
     const int nw = nk_waves_per_wg();
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
     const bool save = act_save != nullptr;
