@@ -60,46 +60,52 @@ NK_D void pe_dir_frags(float dx, float dy, float dz, int h, Frag (&f)[2]) {
         for (int w = 0; w < 4; ++w) f[s].u[w] = pack_bf16(v[8 * s + 2 * w], v[8 * s + 2 * w + 1]);
 }
 
-// The weight stream: stage i sits in ring half (i & 1); a stage is loaded while the previous one
-// is consumed.  All NW waves issue the loads (block b by wave b % NW) and all pass one barrier per
-// stage, which both publishes the landed stage and retires the reads of the one being replaced.
+// The weight stream: stage i sits in LDS ring slot i % 3 and is loaded (LDS-DMA, 16 B per lane)
+// two stages before it is consumed.  All NW waves issue the loads (block b by wave b % NW) and
+// all pass one barrier per stage, which both publishes the landed stage and retires the reads of
+// the slot that the next issue overwrites.
 template <int NW>
 struct WStream {
-    const char* g;      // next byte of the stream to load
-    char* ring;         // LDS base
-    int half_bytes;
-    int cur;            // ring half holding the stage being consumed
+    const char* g;          // next byte of the stream to load
+    char* ring;             // LDS base
+    int slot_bytes;
+    int cur;                // ring slot holding the stage being consumed
+    int nxt;                // ring slot the next issue fills
     int wave, lane;
-    NK_D void issue(int nb) {        // load the next stage (nb blocks) into the other half
-        char* dst = ring + (cur ^ 1) * half_bytes;
+    NK_D void issue_next(int nb) {       // nb = 1-KiB blocks of the stage after next (0: none left)
+        char* dst = ring + nxt * slot_bytes;
         for (int b = wave; b < nb; b += NW)
             __builtin_amdgcn_global_load_lds((const NK_GLB void*)(g + (int64_t)b * 1024 + lane * 16),
                                              (NK_LDS void*)(dst + b * 1024), 16, 0, 0);
         g += (int64_t)nb * 1024;
+        nxt = nxt == 2 ? 0 : nxt + 1;
     }
-    NK_D void flip() {               // end of stage: loaded data visible, old half free
+    NK_D void start(int nb0, int nb1) {      // stages 0 and 1 loaded and visible
+        cur = 0; nxt = 0;
+        issue_next(nb0);
+        issue_next(nb1);
         __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
         __syncthreads();
-        cur ^= 1;
     }
-    // Same, but lets the NST youngest vector-memory operations stay in flight.  vmcnt retires in
-    // issue order, so when the only operations issued after this stage's issue() are NST global
-    // STORES (activation / dZ tiles, which the compiler cannot move above the stream load they may
-    // alias), the stream load has landed once at most NST operations are outstanding.  Passing a
-    // smaller NST than the true count only waits longer; a larger one would race.
-    template <int NST>
+    NK_D void advance() { cur = cur == 2 ? 0 : cur + 1; }
+    // End of stage: wait until at most N vector-memory operations are outstanding, then barrier.
+    // vmcnt retires in issue order, so with N = (operations issued after the NEXT stage's load:
+    // the stores of the previous and of this stage, and this wave's share of the load issued in
+    // this stage for the stage after next) the next stage has landed.  Passing a smaller N than
+    // the true count only waits longer; a larger one would race.
+    template <int N>
     NK_D void flip_keep() {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NST) : "memory");
-        cur ^= 1;
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+        advance();
     }
     // Same, naming the tile's accumulator: its MFMAs are register-only instructions that hipcc
     // otherwise sinks below the barrier, stretching the live range of 16 weight fragments.
-    template <int NST>
+    template <int N>
     NK_D void flip_keep(f32x16& acc) {
-        asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)\n\ts_barrier" : "+v"(acc) : "n"(NST) : "memory");
-        cur ^= 1;
+        asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)\n\ts_barrier" : "+v"(acc) : "n"(N) : "memory");
+        advance();
     }
-    NK_D const char* stage() const { return ring + cur * half_bytes; }
+    NK_D const char* stage() const { return ring + cur * slot_bytes; }
 };
 
 // bias fragment of a stage (block index nk): 16 floats for this lane-half

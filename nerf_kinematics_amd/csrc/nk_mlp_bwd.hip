@@ -270,11 +270,11 @@ extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const vo
     const int nw = nk_waves_per_wg();
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
     if (p.W == 256) {
-        if (nw == 8) hipLaunchKernelGGL((k_mlp_bwd<256, 128, 8>), grid, block, 2 * (16 + 1) * 1024, st, a);
-        else hipLaunchKernelGGL((k_mlp_bwd<256, 128, 4>), grid, block, 2 * (16 + 1) * 1024, st, a);
+        if (nw == 8) hipLaunchKernelGGL((k_mlp_bwd<256, 128, 8>), grid, block, 3 * (16 + 1) * 1024, st, a);
+        else hipLaunchKernelGGL((k_mlp_bwd<256, 128, 4>), grid, block, 3 * (16 + 1) * 1024, st, a);
     } else {
-        if (nw == 8) hipLaunchKernelGGL((k_mlp_bwd<128, 64, 8>), grid, block, 2 * (8 + 1) * 1024, st, a);
-        else hipLaunchKernelGGL((k_mlp_bwd<128, 64, 4>), grid, block, 2 * (8 + 1) * 1024, st, a);
+        if (nw == 8) hipLaunchKernelGGL((k_mlp_bwd<128, 64, 8>), grid, block, 3 * (8 + 1) * 1024, st, a);
+        else hipLaunchKernelGGL((k_mlp_bwd<128, 64, 4>), grid, block, 3 * (8 + 1) * 1024, st, a);
     }
     NK_CHECK_LAUNCH("k_mlp_bwd");
 

@@ -125,6 +125,7 @@ int nk_build_plan(const nk_arch* a, NkPlan* p) {
     for (int i = D - 1; i >= 1; --i)
         add_bwd(i, W / 32, W / 16, (a->skip >= 0 && i == a->skip + 1) ? in_xyz : 0);
     p->bwd_blocks = blk;
+
     return NK_OK;
 }
 

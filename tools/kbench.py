@@ -2,8 +2,10 @@
 import sys, os, math, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import nerf_kinematics_amd as nk
 from nerf_kinematics_amd import lib as L_
+if os.environ.get("NK_LIB"):            # experiment builds (tools/bin/*.so)
+    L_.LIB_PATH = os.path.abspath(os.environ["NK_LIB"])
+import nerf_kinematics_amd as nk
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=16384)
