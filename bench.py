@@ -14,8 +14,9 @@ Every GPU takes --rays rays per step (weak scaling).  value = ray-samples/s = ra
 summed over all GPUs, inputs resident in HBM.
 
 Extra objects on the JSON line:
-  roofline      the fine-network fused MLP forward launch (k_mlp_fwd): algorithmic FLOPs per
-                launch / its mean duration from HIP events recorded around it in the timed steps
+  roofline      the fused MLP forward launches that save activations (k_mlp_fwd<..,true>, two per
+                step): algorithmic bytes per launch / mean launch duration from HIP events recorded
+                around them in the timed steps, against the HBM peak (the roofline that bounds it)
   cpu_baseline  the CPU restatement (oracle, torch CPU fp32) of the same training step, timed on
                 this host on a bounded ray sample (rank 0, N == 1 only)
 """
@@ -34,6 +35,9 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_EVAL_8x256 = 1186816          # forward FLOPs of one 8x256 NeRF evaluation (2 x 593 408 MAC)
 PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA peak
+PEAK_HBM_GBS = 8000.0                  # MI355X HBM3E peak
+ACT_BYTES_PER_POINT = 5056 + 320 + 16  # bytes one 8x256 evaluation writes in training mode (see roofline below)
+PMC_BYTES_PER_POINT = 5401.0           # measured: (WRITE_SIZE + 2 FETCH_SIZE) / points, profiles/r01_pmc_hbm_bytes.csv
 
 
 def parse():
@@ -99,8 +103,9 @@ def main():
     tr = Trainer(nk.ARCH_RUN_NERF, nk.ARCH_RUN_NERF, opts, dev, rays_per_step=a.rays)
     sampler = RaySampler(scene, a.rays, seed=1234, rank=rank, world=world)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    dummy = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    mk_ev = lambda: tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
+    ev = [mk_ev() for _ in range(a.steps)]       # (fine start, fine stop, coarse start, coarse stop) per timed step
+    dummy = mk_ev()
 
     def one_step(i, events):
         rb, target = sampler.next(i)        # one kernel: pixel draw + get_rays + target colours
@@ -126,10 +131,20 @@ def main():
     if rank == 0:
         samples = a.rays * 192 * a.steps * world
         value = samples / dt
-        # dominant kernel: fused MLP forward of the fine network (192 evaluations per ray)
-        k_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
-        flops = a.rays * 192 * FLOP_PER_EVAL_8x256
-        achieved = flops / (k_ms * 1e-3) / 1e12
+        # Roofline kernel: k_mlp_fwd<256,128,4,true>, the fused Embedder + MLP forward that saves bf16
+        # activations for backward; two launches per step (coarse: 64 evaluations per ray, fine: 192).
+        # Per point it does 1 186 816 FLOP and moves 5 392 B (5 056 B of bf16 activations + 320 B of
+        # ReLU bit words written, 16 B of raw output written; rays / depths / the L2-resident weight
+        # stream are noise): 0.47 ns at the MFMA peak, 0.67 ns at the HBM peak -- HBM is the roofline
+        # that bounds it.  The launch duration is the mean over both launches of every timed step
+        # (HIP events on the launch stream), which is what a kernel trace averages too.
+        t_f = [e[0].elapsed_time(e[1]) for e in ev]
+        t_c = [e[2].elapsed_time(e[3]) for e in ev]
+        k_ms = float(np.mean(t_f + t_c))
+        pts = a.rays * (64 + 192) / 2.0                         # points per launch, averaged like k_ms
+        bytes_per_launch = pts * ACT_BYTES_PER_POINT
+        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        flops = pts * FLOP_PER_EVAL_8x256
         res = {
             "metric": "ray-samples/sec (train)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -138,10 +153,14 @@ def main():
                                    f"train step (fwd+bwd+Adam), {a.rays} rays/step/GPU",
                        "rays_per_step_per_gpu": a.rays, "num_coarse": 64, "num_fine": 128,
                        "mlp_evals_per_s": value / 192 * 256, "final_loss": float(loss)},
-            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<256,128> (fine network, 192 evals/ray)",
-                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None, "kernel_ms": k_ms,
-                         "flop_per_launch": flops,
+            "roofline": {"bound": "hbm", "kernel": "k_mlp_fwd<256,128,4,true> (Embedder + MLP forward, activations saved)",
+                         "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                         # HBM bytes per launch from the PMC passes kept under profiles/ (WRITE_SIZE +
+                         # 2 x FETCH_SIZE of the fine launch, scaled to this mean launch): all of it algorithmic
+                         "traffic": pts * PMC_BYTES_PER_POINT,
+                         "kernel_ms": k_ms, "kernel_ms_fine": float(np.mean(t_f)), "kernel_ms_coarse": float(np.mean(t_c)),
+                         "bytes_per_launch": bytes_per_launch, "flop_per_launch": flops,
+                         "mfma_tflops": flops / (k_ms * 1e-3) / 1e12, "mfma_frac": flops / (k_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                          "step_train_tflops": samples / dt * 3 * FLOP_PER_EVAL_8x256 * 256 / 192 / 1e12},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -218,8 +218,11 @@ static int launch_gemm(const NkPlan& p, const char* A, int MA, const char* B, in
     GemmArgs g;
     g.A = A; g.B = B; g.MT = MA / 32; g.NT = NB / 32;
     g.n_stages = G;
-    static const int target_wgs = []() { const char* e = getenv("NK_GEMM_WGS"); const int v = e ? atoi(e) : 0;
-                                         return v > 0 ? v : 256; }();
+    // Split-K width: one workgroup per CU for large batches; fewer when a workgroup would see less
+    // than ~48 stages, because every workgroup pays the same atomic epilogue (one output matrix).
+    static const int env_wgs = []() { const char* e = getenv("NK_GEMM_WGS"); return e ? atoi(e) : 0; }();
+    int64_t target_wgs = env_wgs > 0 ? env_wgs : g.n_stages / 48;
+    if (env_wgs <= 0) target_wgs = target_wgs < 64 ? 64 : (target_wgs > 256 ? 256 : target_wgs);
     g.stages_per_wg = (g.n_stages + target_wgs - 1) / target_wgs;
     if (g.stages_per_wg < 1) g.stages_per_wg = 1;
     g.grad = grad; g.w_off = w_off; g.ld = ld; g.row_first = row_first; g.row_count = row_count; g.row_dst0 = row_dst0;

@@ -125,8 +125,10 @@ class Trainer:
         s = self._stage
         rb = ray_batch.data_ptr()
         _lib.check(L.nk_stratified_z(rb, R, o, s["z_c"].data_ptr(), st))
+        events[2].record()
         _lib.check(L.nk_mlp_forward(self.coarse._c, self.coarse.packed.data_ptr(), rb, s["z_c"].data_ptr(), R, Nc,
                                     s["raw_c"].data_ptr(), s["act_c"].data_ptr(), st))
+        events[3].record()
         _lib.check(L.nk_raw2outputs(s["raw_c"].data_ptr(), s["z_c"].data_ptr(), rb, R, Nc, o, _lib.STREAM_NOISE_COARSE,
                                     self.rgb_c.data_ptr(), None, None, None, s["w_c"].data_ptr(), st))
         _lib.check(L.nk_sample_pdf(s["z_c"].data_ptr(), s["w_c"].data_ptr(), R, o, s["z_all"].data_ptr(), None, st))
@@ -156,8 +158,9 @@ class Trainer:
     def step(self, ray_batch: torch.Tensor, target: torch.Tensor, events=None) -> torch.Tensor:
         """ray_batch [R,11], target [R,3] on this GPU; returns the loss tensor (device, no sync).
 
-        ``events``: optional (start, stop) torch.cuda.Event pair recorded around the fine-network MLP
-        forward launch; the step then issues the same kernels stage by stage."""
+        ``events``: optional four torch.cuda.Event objects recorded around the fine-network (0, 1) and
+        the coarse-network (2, 3) MLP forward launches; the step then issues the same kernels stage
+        by stage."""
         L, dev = self.L, self.device
         R = ray_batch.shape[0]
         if R != self.R:
