@@ -29,17 +29,25 @@ struct BwdArgs {
 // --------------------------------------------------------------------------------------------
 enum { NK_COL_IDENT = 0, NK_COL_PEX = 1, NK_COL_PED = 2 };
 
+// Where the product of one A segment (rows) and one B segment (columns) is accumulated.
+struct GemmDst {
+    int enabled;
+    int w_off, ld;                          // destination matrix origin and leading dimension
+    int row_first, row_count, row_dst0;     // segment rows [row_first, +row_count) -> matrix rows row_dst0..
+    int colmode, col_base, col_count, nfreq;
+};
+
+// A and B are each one or two regions ([G][tiles*4][32][8] bf16) laid side by side, so that GEMMs
+// sharing an operand (a skip layer's two inputs, the view layer's two inputs) read it from HBM
+// once.
 struct GemmArgs {
-    const char* A; const char* B;   // regions [G][MT*4][32][8], [G][NT*4][32][8] bf16
-    int MT, NT;                     // 32-wide tiles of A features / B features
-    int WM, WN;                     // wave grid (WM*WN <= 8); wave tile = (MT/WM) x (NT/WN) tiles
+    const char* A[2]; int MA0;      // A tiles [0, MA0) come from A[0], the rest from A[1]
+    const char* B[2]; int NB0;
     int64_t n_stages;               // G (a stage = 1 group = 32 points)
     int64_t stages_per_wg;
     float* grad;                    // flat gradient
-    int w_off, ld;                  // destination matrix origin and leading dimension
-    int row_first, row_count, row_dst0;
-    int colmode, col_base, col_count, nfreq;
-    int b_off;                      // bias gradient origin, or -1
+    GemmDst dst[2][2];              // [A segment][B segment]
+    int b_off[2];                   // bias gradient origin per A segment (rows as dst[seg][0]), or -1
 };
 
 // Transposed LDS reads are issued from inline asm: hipcc drains vmcnt before a
@@ -108,8 +116,11 @@ __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmArgs a) {
             if (b >= blocks_per_stage) break;
             const bool isA = b < MT * 2;
             const int pb = isA ? b : b - MT * 2;            // 1-KiB block inside the piece
-            const char* src = isA ? a.A + stage * MT * 2048 : a.B + stage * NT * 2048;
-            const int o = 2 * pb + (lane >> 5), cpos = lane & 31;
+            const int t0 = isA ? a.MA0 : a.NB0;             // tiles of the piece's first segment
+            const int seg = pb >= 2 * t0;
+            const int seg_tiles = seg ? (isA ? MT : NT) - t0 : t0;
+            const char* src = (isA ? a.A[seg] : a.B[seg]) + stage * seg_tiles * 2048;
+            const int o = 2 * (pb - (seg ? 2 * t0 : 0)) + (lane >> 5), cpos = lane & 31;   // octet inside the segment
             const int csrc = cpos ^ ((o & 3) << 2);           // swizzle on the source side
             __builtin_amdgcn_global_load_lds((const NK_GLB void*)(src + (o * 32 + csrc) * 16),
                                              (NK_LDS void*)(dst + b * 1024), 16, 0, 0);
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) bsum[i] = 0.0f;
     bf16x2 ones; ones[0] = (__bf16)1.0f; ones[1] = (__bf16)1.0f;
-    const bool want_bias = a.b_off >= 0;
+    const bool want_bias = a.b_off[0] >= 0 || a.b_off[1] >= 0;
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)(NK_LDS char*)lds;
     for (int64_t s = s0; s < s0 + 3 && s < s1; ++s) issue(s);
@@ -182,41 +193,66 @@ __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmArgs a) {
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = 32 * (wn * TN + j) + r;
-        int dcol = -1;
-        if (a.colmode == NK_COL_IDENT) dcol = n < a.col_count ? a.col_base + n : -1;
-        else {
-            const int s = n >> 4, hh = (n >> 3) & 1, jj = n & 7;
-            const int cc = a.colmode == NK_COL_PEX ? (s < 4 ? nk_pe_xyz_col(8 * s + jj, hh, a.nfreq) : -1)
-                                                   : (s < 2 ? nk_pe_dir_col(8 * s + jj, hh, a.nfreq) : -1);
-            dcol = cc >= 0 ? a.col_base + cc : -1;
-        }
+        const int nt = wn * TN + j;
+        const int sb = nt >= a.NB0;
+        const int n = 32 * (nt - (sb ? a.NB0 : 0)) + r;         // column inside the B segment
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int mt = wm * TM + i;
+            const int sa = mt >= a.MA0;
+            const GemmDst& d = a.dst[sa][sb];
+            if (!d.enabled) continue;
+            int dcol = -1;
+            if (d.colmode == NK_COL_IDENT) dcol = n < d.col_count ? d.col_base + n : -1;
+            else {
+                const int s = n >> 4, hh = (n >> 3) & 1, jj = n & 7;
+                const int cc = d.colmode == NK_COL_PEX ? (s < 4 ? nk_pe_xyz_col(8 * s + jj, hh, d.nfreq) : -1)
+                                                       : (s < 2 ? nk_pe_dir_col(8 * s + jj, hh, d.nfreq) : -1);
+                dcol = cc >= 0 ? d.col_base + cc : -1;
+            }
+            if (dcol < 0) continue;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = 32 * (wm * TM + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int mr = m - a.row_first;
-                if (dcol >= 0 && mr >= 0 && mr < a.row_count)
-                    atomicAdd(a.grad + a.w_off + (int64_t)(a.row_dst0 + mr) * a.ld + dcol, acc[i][j][e]);
+                const int m = 32 * (mt - (sa ? a.MA0 : 0)) + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int mr = m - d.row_first;
+                if (mr >= 0 && mr < d.row_count)
+                    atomicAdd(a.grad + d.w_off + (int64_t)(d.row_dst0 + mr) * d.ld + dcol, acc[i][j][e]);
             }
         }
     }
     if (want_bias) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int mt = wm * TM + i;
+            const int sa = mt >= a.MA0;
+            const GemmDst& d = a.dst[sa][0];
             const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-            const int m = 32 * (wm * TM + i) + r, mr = m - a.row_first;
-            if (h == 0 && mr >= 0 && mr < a.row_count) atomicAdd(a.grad + a.b_off + a.row_dst0 + mr, tot);
+            const int m = 32 * (mt - (sa ? a.MA0 : 0)) + r, mr = m - d.row_first;
+            if (a.b_off[sa] >= 0 && h == 0 && mr >= 0 && mr < d.row_count)
+                atomicAdd(a.grad + a.b_off[sa] + d.row_dst0 + mr, tot);
         }
     }
 }
 
-static int launch_gemm(const NkPlan& p, const char* A, int MA, const char* B, int NB, int64_t G, float* grad,
-                       int w_off, int ld, int row_first, int row_count, int row_dst0, int colmode, int col_base,
-                       int col_count, int nfreq, int b_off, hipStream_t stream) {
+static GemmDst gemm_dst(int w_off, int ld, int row_first, int row_count, int colmode, int col_base, int col_count,
+                        int nfreq) {
+    GemmDst d;
+    d.enabled = 1; d.w_off = w_off; d.ld = ld; d.row_first = row_first; d.row_count = row_count; d.row_dst0 = 0;
+    d.colmode = colmode; d.col_base = col_base; d.col_count = col_count; d.nfreq = nfreq;
+    return d;
+}
+
+// A0 (+A1) against B0 (+B1); widths in features (multiples of 32, 0 = segment absent)
+static int launch_gemm(const char* A0, int wA0, const char* A1, int wA1, const char* B0, int wB0, const char* B1,
+                       int wB1, int64_t G, float* grad, const GemmDst (&dst)[2][2], int b_off0, int b_off1,
+                       hipStream_t stream) {
     GemmArgs g;
-    g.A = A; g.B = B; g.MT = MA / 32; g.NT = NB / 32;
+    g.A[0] = A0; g.A[1] = A1 ? A1 : A0; g.MA0 = wA0 / 32;
+    g.B[0] = B0; g.B[1] = B1 ? B1 : B0; g.NB0 = wB0 / 32;
+    const int MT = (wA0 + wA1) / 32, NT = (wB0 + wB1) / 32;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) g.dst[i][j] = dst[i][j];
+    g.b_off[0] = b_off0; g.b_off[1] = b_off1;
     g.n_stages = G;
     // Split-K width: one workgroup per CU for large batches; fewer when a workgroup would see less
     // than ~48 stages, because every workgroup pays the same atomic epilogue (one output matrix).
@@ -225,26 +261,26 @@ static int launch_gemm(const NkPlan& p, const char* A, int MA, const char* B, in
     if (env_wgs <= 0) target_wgs = target_wgs < 64 ? 64 : (target_wgs > 256 ? 256 : target_wgs);
     g.stages_per_wg = (g.n_stages + target_wgs - 1) / target_wgs;
     if (g.stages_per_wg < 1) g.stages_per_wg = 1;
-    g.grad = grad; g.w_off = w_off; g.ld = ld; g.row_first = row_first; g.row_count = row_count; g.row_dst0 = row_dst0;
-    g.colmode = colmode; g.col_base = col_base; g.col_count = col_count; g.nfreq = nfreq; g.b_off = b_off;
+    g.grad = grad;
     const unsigned nwg = (unsigned)((g.n_stages + g.stages_per_wg - 1) / g.stages_per_wg);
-    const int lds_bytes = NK_GEMM_RING * (g.MT + g.NT) * 2048;
+    const int lds_bytes = NK_GEMM_RING * (MT + NT) * 2048;
     const dim3 grid(nwg), block(512);
     // (A tiles, B tiles) -> wave grid; every shape the supported networks produce
 #define NK_GEMM_CASE(MT_, NT_, WM_, WN_) \
-    if (g.MT == MT_ && g.NT == NT_) { \
-        g.WM = WM_; g.WN = WN_; \
+    if (MT == MT_ && NT == NT_) { \
         NK_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_gemm<MT_, NT_, WM_, WN_>, \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
         hipLaunchKernelGGL((k_dw_gemm<MT_, NT_, WM_, WN_>), grid, block, lds_bytes, stream, g); \
     } else
-    NK_GEMM_CASE(8, 8, 2, 4) NK_GEMM_CASE(8, 2, 4, 2) NK_GEMM_CASE(4, 8, 2, 4) NK_GEMM_CASE(4, 4, 2, 4)
-    NK_GEMM_CASE(1, 4, 1, 4) NK_GEMM_CASE(1, 8, 1, 8) NK_GEMM_CASE(4, 1, 4, 1)
-    NK_GEMM_CASE(4, 2, 4, 2) NK_GEMM_CASE(2, 4, 2, 4) NK_GEMM_CASE(1, 2, 1, 2) NK_GEMM_CASE(2, 1, 2, 1)
-    NK_FAIL(NK_ERR_UNSUPPORTED, "dW GEMM: no kernel for %d x %d tiles", g.MT, g.NT);
+    // width 256: trunk / feature, trunk 0, rgb, alpha, skip (h + gamma(x)), views (feat + gamma(d))
+    NK_GEMM_CASE(8, 8, 2, 4) NK_GEMM_CASE(8, 2, 4, 2) NK_GEMM_CASE(1, 4, 1, 4) NK_GEMM_CASE(1, 8, 1, 8)
+    NK_GEMM_CASE(8, 10, 4, 2) NK_GEMM_CASE(4, 9, 2, 3)
+    // width 128: the same six ((1, 4) doubles as its alpha shape)
+    NK_GEMM_CASE(4, 4, 2, 4) NK_GEMM_CASE(4, 2, 4, 2) NK_GEMM_CASE(1, 2, 1, 2)
+    NK_GEMM_CASE(4, 6, 2, 2) NK_GEMM_CASE(2, 5, 2, 1)
+    NK_FAIL(NK_ERR_UNSUPPORTED, "dW GEMM: no kernel for %d x %d tiles", MT, NT);
 #undef NK_GEMM_CASE
     NK_CHECK_LAUNCH("k_dw_gemm");
-    (void)p;
     return NK_OK;
 }
 
@@ -281,7 +317,7 @@ extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const vo
     }
     NK_CHECK_LAUNCH("k_mlp_bwd");
 
-    // weight / bias gradients, one GEMM per (dZ, layer input) pair
+    // weight / bias gradients: one GEMM per dZ tensor, with operands that two layers share read once
     const int D = p.D, W = p.W, WD = p.WD;
     const int64_t G = a.G;
     auto act = [&](int idx) { return a.act + nk_act_offset(p, idx, G); };
@@ -290,39 +326,46 @@ extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const vo
     const NkLayer& lviews = p.layer[D + 2];
     const NkLayer& lfeat = p.layer[D + 1];
     const NkLayer& lalpha = p.layer[D];
-    // rgb: rows 0..2 of dOut against g
-    rc = launch_gemm(p, dz(0), 32, act(3 + D), WD, G, grad, lrgb.w_off, lrgb.in_dim, 0, 3, 0, NK_COL_IDENT, 0, WD, 0,
-                     lrgb.b_off, st);
-    if (rc < 0) return rc;
-    // alpha: row 3 of dOut against h_{D-1}
-    rc = launch_gemm(p, dz(0), 32, act(2 + D - 1), W, G, grad, lalpha.w_off, lalpha.in_dim, 3, 1, 0, NK_COL_IDENT, 0, W,
-                     0, lalpha.b_off, st);
-    if (rc < 0) return rc;
-    // views: dZ_views against cat[feat, gamma(d)]
-    rc = launch_gemm(p, dz(1), WD, act(2 + D), W, G, grad, lviews.w_off, lviews.in_dim, 0, WD, 0, NK_COL_IDENT, 0, W, 0,
-                     lviews.b_off, st);
-    if (rc < 0) return rc;
-    rc = launch_gemm(p, dz(1), WD, act(1), 32, G, grad, lviews.w_off, lviews.in_dim, 0, WD, 0, NK_COL_PED, W, 32, p.Ld,
-                     -1, st);
-    if (rc < 0) return rc;
-    // feat: dZ_feat against h_{D-1}
-    rc = launch_gemm(p, dz(2), W, act(2 + D - 1), W, G, grad, lfeat.w_off, lfeat.in_dim, 0, W, 0, NK_COL_IDENT, 0, W, 0,
-                     lfeat.b_off, st);
-    if (rc < 0) return rc;
-    // trunk
-    for (int L = D - 1; L >= 0; --L) {
+    const int pex0 = 3 + 6 * p.Lx;          // width of gamma(x) inside a skip layer's input
+    {   // rgb: rows 0..2 of dOut against g
+        GemmDst d[2][2] = {};
+        d[0][0] = gemm_dst(lrgb.w_off, lrgb.in_dim, 0, 3, NK_COL_IDENT, 0, WD, 0);
+        rc = launch_gemm(dz(0), 32, nullptr, 0, act(3 + D), WD, nullptr, 0, G, grad, d, lrgb.b_off, -1, st);
+        if (rc < 0) return rc;
+    }
+    {   // views: dZ_views against cat[feat, gamma(d)]
+        GemmDst d[2][2] = {};
+        d[0][0] = gemm_dst(lviews.w_off, lviews.in_dim, 0, WD, NK_COL_IDENT, 0, W, 0);
+        d[0][1] = gemm_dst(lviews.w_off, lviews.in_dim, 0, WD, NK_COL_PED, W, 32, p.Ld);
+        rc = launch_gemm(dz(1), WD, nullptr, 0, act(2 + D), W, act(1), 32, G, grad, d, lviews.b_off, -1, st);
+        if (rc < 0) return rc;
+    }
+    {   // alpha: row 3 of dOut against h_{D-1}
+        GemmDst d[2][2] = {};
+        d[0][0] = gemm_dst(lalpha.w_off, lalpha.in_dim, 3, 1, NK_COL_IDENT, 0, W, 0);
+        rc = launch_gemm(dz(0), 32, nullptr, 0, act(2 + D - 1), W, nullptr, 0, G, grad, d, lalpha.b_off, -1, st);
+        if (rc < 0) return rc;
+    }
+    {   // feature layer: dZ_feat against h_{D-1}
+        GemmDst d[2][2] = {};
+        d[0][0] = gemm_dst(lfeat.w_off, lfeat.in_dim, 0, W, NK_COL_IDENT, 0, W, 0);
+        rc = launch_gemm(dz(2), W, nullptr, 0, act(2 + D - 1), W, nullptr, 0, G, grad, d, lfeat.b_off, -1, st);
+        if (rc < 0) return rc;
+    }
+    for (int L = D - 1; L >= 0; --L) {     // trunk
         const NkLayer& l = p.layer[L];
         const char* dzl = dz(3 + D - 1 - L);
+        GemmDst d[2][2] = {};
         if (L == 0) {
-            rc = launch_gemm(p, dzl, W, act(0), 64, G, grad, l.w_off, l.in_dim, 0, W, 0, NK_COL_PEX, 0, 64, p.Lx, l.b_off, st);
+            d[0][0] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_PEX, 0, 64, p.Lx);
+            rc = launch_gemm(dzl, W, nullptr, 0, act(0), 64, nullptr, 0, G, grad, d, l.b_off, -1, st);
         } else if (p.skip >= 0 && L == p.skip + 1) {
-            rc = launch_gemm(p, dzl, W, act(0), 64, G, grad, l.w_off, l.in_dim, 0, W, 0, NK_COL_PEX, 0, 64, p.Lx, -1, st);
-            if (rc < 0) return rc;
-            rc = launch_gemm(p, dzl, W, act(2 + L - 1), W, G, grad, l.w_off, l.in_dim, 0, W, 0, NK_COL_IDENT,
-                             3 + 6 * p.Lx, W, 0, l.b_off, st);
+            d[0][0] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_IDENT, pex0, W, 0);
+            d[0][1] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_PEX, 0, 64, p.Lx);
+            rc = launch_gemm(dzl, W, nullptr, 0, act(2 + L - 1), W, act(0), 64, G, grad, d, l.b_off, -1, st);
         } else {
-            rc = launch_gemm(p, dzl, W, act(2 + L - 1), W, G, grad, l.w_off, l.in_dim, 0, W, 0, NK_COL_IDENT, 0, W, 0,
-                             l.b_off, st);
+            d[0][0] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_IDENT, 0, W, 0);
+            rc = launch_gemm(dzl, W, nullptr, 0, act(2 + L - 1), W, nullptr, 0, G, grad, d, l.b_off, -1, st);
         }
         if (rc < 0) return rc;
     }
