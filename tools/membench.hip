@@ -75,6 +75,22 @@ __global__ __launch_bounds__(256) void k_rv16(const char* src, int64_t kib_per_w
     if (sink && (acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[1] = 1;
 }
 
+// bare MFMA loop: 4 independent 32x32x16 bf16 chains per wave, operands in registers
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__global__ __launch_bounds__(256) void k_mfma(float* out, int iters) {
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * (i + 1)); }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+    }
+    if (c0[0] + c1[1] + c2[2] + c3[3] == 1.2345f) out[0] = 1.0f;
+}
+
 template <typename F>
 static void run(const char* name, double bytes, F launch) {
     hipEvent_t e0, e1;
@@ -113,6 +129,18 @@ int main() {
         char nm[64];
         snprintf(nm, 64, "r16 lds %d wgs", wgs);
         run(nm, (double)waves * kib * 1024, [&] { hipLaunchKernelGGL(k_r16, dim3(wgs), dim3(512), 65536, 0, buf, kib, sink); });
+    }
+    for (int wpc : {4, 8}) {     // waves per CU: 1 or 2 per SIMD
+        const int iters = 20000, wgs = 256 * wpc / 4;
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_mfma, dim3(wgs), dim3(256), 0, 0, (float*)sink, 100); CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_mfma, dim3(wgs), dim3(256), 0, 0, (float*)sink, iters);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double flop = (double)wgs * 4 * iters * 4 * 2.0 * 32 * 32 * 16;
+        printf("mfma bf16 32x32x16, %d waves/CU  %8.3f ms  %7.1f TFLOP/s\n", wpc, ms, flop / (ms * 1e-3) / 1e12);
     }
     return 0;
 }
