@@ -1,0 +1,95 @@
+"""Two ranks of the real Trainer (HIP path) on ONE GPU, exchanging the flat gradient over gloo:
+the data-parallel step must equal the single-process step on the concatenated batch, and every
+rank must hold bit-identical parameters afterwards.  (RCCL needs one GPU per rank; the exchange
+itself is backend-independent: one all-reduce of one flat fp32 buffer.)"""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+R = 512
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _make_trainer(rays, dev):
+    import nerf_kinematics_amd as nk
+    from nerf_kinematics_amd import checkpoint as ckpt
+    from nerf_kinematics_amd.trainer import Trainer, TrainOpts
+    # no jitter / noise: their random draws are indexed by the position of a ray in the local batch
+    opts = TrainOpts(num_coarse=64, num_fine=64, num_random_rays=rays, perturb=False, radiance_field_noise_std=0.0,
+                     lr=5e-3, seed=42)
+    tr = Trainer(nk.ARCH_LEGO_CKPT, nk.ARCH_LEGO_CKPT, opts, dev)
+    w = np.load(os.path.join(HERE, "golden", "lego_lowres3_weights.npz"))      # trained: rays hit density
+    tr.import_state(ckpt.TrainState(0, torch.from_numpy(w["coarse"]), torch.from_numpy(w["fine"]), [], [], 0, 5e-3))
+    return tr
+
+
+def _batch(dev):
+    from nerf_kinematics_amd import datasets
+    focal = 0.5 * 64 / math.tan(0.5 * datasets.LEGO_CAMERA_ANGLE_X)
+    sc = datasets.Scene(None, datasets.spherical_pose(45.0, -30.0, 4.0)[None], 64, 64, focal, focal, 32.0, 32.0, 2.0, 6.0)
+    g = torch.Generator().manual_seed(5)
+    sel = torch.randperm(64 * 64, generator=g)[:R]
+    return sc.rays(0, dev)[sel.to(dev)].contiguous(), torch.rand(R, 3, generator=g).to(dev)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    from nerf_kinematics_amd import dist as nd
+    nd.init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    tr = _make_trainer(R // world, dev)
+    assert tr.world == world
+    rb, target = _batch(dev)
+    sl = nd.shard_rows(R, rank, world)
+    loss = float(tr.step(rb[sl].contiguous(), target[sl].contiguous()))
+    in_sync = nd.params_in_sync(tr.params)
+    q.put((rank, loss, tr.grad.cpu().numpy().copy(), tr.params.cpu().numpy().copy(), in_sync))
+    torch.distributed.barrier()
+    nd.shutdown()
+
+
+def test_two_rank_trainer_step_equals_single_process():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU and the HIP library; there is no CPU fallback")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, loss, grad, params, ok = q.get(timeout=300)
+        got[rank] = (loss, torch.from_numpy(grad), torch.from_numpy(params), ok)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    one = _make_trainer(R, dev)
+    rb, target = _batch(dev)
+    loss1 = float(one.step(rb, target))
+    g1, p1 = one.grad.cpu(), one.params.cpu()
+    assert float(g1.norm()) > 0
+    # every rank holds the same summed gradient and bit-identical parameters
+    assert got[0][3] and got[1][3]
+    assert torch.equal(got[0][1], got[1][1]) and torch.equal(got[0][2], got[1][2])
+    # mean of the per-rank losses / gradients = full-batch loss / gradient (fp32 atomics: 1e-4)
+    assert abs(0.5 * (got[0][0] + got[1][0]) - loss1) < 1e-5 * abs(loss1) + 1e-7
+    g2 = got[0][1] / 2
+    assert float((g2 - g1).norm() / g1.norm()) < 1e-4
+    # ... and the same Adam step (first step moves every parameter by ~lr; near-zero gradients may flip)
+    d = (got[0][2] - p1).abs()
+    assert float(d.mean()) < 1e-5 and float(d.max()) <= 2 * 5e-3 + 1e-6
