@@ -10,8 +10,9 @@
 // A-operand fragments with the matching permutation (k_pack_weights), in the exact order the
 // kernel consumes them, so the weight side is a linear stream: global -> LDS by
 // global_load_lds_dwordx4 (one fragment per wave-instruction), LDS -> VGPR by ds_read_b128.
-// A workgroup is 8 wavefronts = 256 points sharing one pass over the stream; the stream is
-// double-buffered per output tile (stage), one barrier per stage.
+// A workgroup is 4 wavefronts = 128 points sharing one pass over the stream (two workgroups per
+// CU run out of phase); the stream goes through a three-slot LDS ring, one stage per output tile
+// (several tiles for the thin first layer), one barrier per stage.
 #include "nk_common.h"
 #include "nk_mfma.h"
 
