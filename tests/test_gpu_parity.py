@@ -353,3 +353,42 @@ def test_full_size_image_properties(nk, dev, lego_w):
         n3 = render(160000, perturb=True, radiance_field_noise_std=0.2, seed=8)
     assert torch.equal(n1[0], n2[0]) and not torch.equal(n1[0], n3[0])
     assert float((n1[0] - whole[0]).abs().mean()) < 0.01
+
+
+def test_maximum_sizes_and_empty_inputs(nk, dev, lego_w):
+    """Edges of the supported range: 512 samples per ray through compositing (forward + backward),
+    256 + 256 through sample_pdf and a whole render; one sample more is refused with a message, not
+    computed wrongly; empty ray batches are refused before any launch."""
+    from nerf_kinematics_amd.lib import NerfKinError
+    torch.manual_seed(3)
+    R = 9
+    rb, _, _ = probe_rays(8, 8)
+    rb = rb[:R].contiguous()
+    z = torch.sort(torch.rand(R, 512) * 4 + 2, -1)[0]
+    raw = torch.randn(R, 512, 4)
+    opts = nk.make_opts(64, 128)
+    raw_ref = raw.clone().requires_grad_(True)
+    rgb, disp, acc, w, depth = O.raw2outputs(raw_ref, z, rb[:, 3:6], None, False)
+    out = nk.raw2outputs(raw.to(dev), z.to(dev), rb.to(dev), opts)
+    np.testing.assert_allclose(out["rgb"].cpu().numpy(), rgb.detach().numpy(), rtol=5e-5, atol=5e-6)
+    np.testing.assert_allclose(out["weights"].cpu().numpy(), w.detach().numpy(), rtol=5e-5, atol=5e-6)
+    g = torch.randn(R, 3)
+    (rgb * g).sum().backward()
+    d_raw = nk.raw2outputs_backward(raw.to(dev), z.to(dev), rb.to(dev), opts, O.STREAM_NOISE_FINE, g.to(dev)).cpu()
+    assert float((d_raw - raw_ref.grad).abs().max()) <= 3e-4 * float(raw_ref.grad.abs().max()) + 1e-7
+    with pytest.raises(NerfKinError, match="max 512"):
+        nk.raw2outputs(torch.zeros(R, 513, 4, device=dev), torch.zeros(R, 513, device=dev), rb.to(dev), opts)
+    # hierarchical sampling and a render at 256 + 256
+    c = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["coarse"]).to(dev))
+    f = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["fine"]).to(dev))
+    with torch.no_grad():
+        big = nk.render_rays(rb.to(dev), c, f, num_coarse=256, num_fine=256)
+        ref = nk.render_rays(rb.to(dev), c, f, num_coarse=64, num_fine=128)
+    assert float((big[0] - ref[0]).abs().max()) < 0.05            # the same scene, sampled four times as densely
+    with pytest.raises(NerfKinError):
+        nk.render_rays(rb.to(dev), c, f, num_coarse=256, num_fine=257)
+    # empty inputs
+    with pytest.raises(ValueError):
+        nk.render_rays(torch.zeros(0, 11, device=dev), c, f, num_coarse=64, num_fine=128)
+    with pytest.raises(ValueError):
+        nk.stratified_z(torch.zeros(0, 11, device=dev), opts)
