@@ -91,8 +91,16 @@ NK_D void gemm_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// Up to NK_GEMM_BATCH products of one shape per launch (blockIdx.y picks the product): a
+// workgroup of the next product starts on a CU as soon as that CU's workgroup of the previous one
+// has retired, so the load ramp-up and the atomic epilogue of one product overlap the main loop
+// of another instead of idling the memory system between launches.
+enum { NK_GEMM_BATCH = 8 };
+struct GemmBatch { GemmArgs g[NK_GEMM_BATCH]; };
+
 template <int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmArgs a) {
+__global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
+    const GemmArgs& a = batch.g[blockIdx.y];
     constexpr int TM = MT / WM, TN = NT / WN;       // wave tile, in 32x32 tiles
     static_assert(TM * WM == MT && TN * WN == NT && WM * WN <= 8, "wave grid must tile the output");
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -242,14 +250,21 @@ static GemmDst gemm_dst(int w_off, int ld, int row_first, int row_count, int col
     return d;
 }
 
+// Products queued by nk_mlp_backward, launched shape by shape.
+struct GemmQueue {
+    GemmArgs g[16];
+    int MT[16], NT[16];
+    int n = 0;
+};
+
 // A0 (+A1) against B0 (+B1); widths in features (multiples of 32, 0 = segment absent)
-static int launch_gemm(const char* A0, int wA0, const char* A1, int wA1, const char* B0, int wB0, const char* B1,
-                       int wB1, int64_t G, float* grad, const GemmDst (&dst)[2][2], int b_off0, int b_off1,
-                       hipStream_t stream) {
-    GemmArgs g;
+static void queue_gemm(GemmQueue& q, const char* A0, int wA0, const char* A1, int wA1, const char* B0, int wB0,
+                       const char* B1, int wB1, int64_t G, float* grad, const GemmDst (&dst)[2][2], int b_off0,
+                       int b_off1) {
+    GemmArgs& g = q.g[q.n];
     g.A[0] = A0; g.A[1] = A1 ? A1 : A0; g.MA0 = wA0 / 32;
     g.B[0] = B0; g.B[1] = B1 ? B1 : B0; g.NB0 = wB0 / 32;
-    const int MT = (wA0 + wA1) / 32, NT = (wB0 + wB1) / 32;
+    q.MT[q.n] = (wA0 + wA1) / 32; q.NT[q.n] = (wB0 + wB1) / 32;
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j) g.dst[i][j] = dst[i][j];
     g.b_off[0] = b_off0; g.b_off[1] = b_off1;
@@ -262,25 +277,40 @@ static int launch_gemm(const char* A0, int wA0, const char* A1, int wA1, const c
     g.stages_per_wg = (g.n_stages + target_wgs - 1) / target_wgs;
     if (g.stages_per_wg < 1) g.stages_per_wg = 1;
     g.grad = grad;
-    const unsigned nwg = (unsigned)((g.n_stages + g.stages_per_wg - 1) / g.stages_per_wg);
-    const int lds_bytes = NK_GEMM_RING * (MT + NT) * 2048;
-    const dim3 grid(nwg), block(512);
-    // (A tiles, B tiles) -> wave grid; every shape the supported networks produce
+    ++q.n;
+}
+
+static int flush_gemms(GemmQueue& q, hipStream_t stream) {
+    bool done[16] = {};
+    for (int first = 0; first < q.n; ++first) {
+        if (done[first]) continue;
+        const int MT = q.MT[first], NT = q.NT[first];
+        GemmBatch batch;
+        int count = 0;
+        for (int k = first; k < q.n && count < NK_GEMM_BATCH; ++k)
+            if (!done[k] && q.MT[k] == MT && q.NT[k] == NT) { batch.g[count++] = q.g[k]; done[k] = true; }
+        for (int k = count; k < NK_GEMM_BATCH; ++k) batch.g[k] = batch.g[0];
+        const GemmArgs& g = batch.g[0];
+        const unsigned nwg = (unsigned)((g.n_stages + g.stages_per_wg - 1) / g.stages_per_wg);
+        const int lds_bytes = NK_GEMM_RING * (MT + NT) * 2048;
+        const dim3 grid(nwg, count), block(512);
+        // (A tiles, B tiles) -> wave grid; every shape the supported networks produce
 #define NK_GEMM_CASE(MT_, NT_, WM_, WN_) \
-    if (MT == MT_ && NT == NT_) { \
-        NK_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_gemm<MT_, NT_, WM_, WN_>, \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
-        hipLaunchKernelGGL((k_dw_gemm<MT_, NT_, WM_, WN_>), grid, block, lds_bytes, stream, g); \
-    } else
-    // width 256: trunk / feature, trunk 0, rgb, alpha, skip (h + gamma(x)), views (feat + gamma(d))
-    NK_GEMM_CASE(8, 8, 2, 4) NK_GEMM_CASE(8, 2, 4, 2) NK_GEMM_CASE(1, 4, 1, 4) NK_GEMM_CASE(1, 8, 1, 8)
-    NK_GEMM_CASE(8, 10, 4, 2) NK_GEMM_CASE(4, 9, 2, 3)
-    // width 128: the same six ((1, 4) doubles as its alpha shape)
-    NK_GEMM_CASE(4, 4, 2, 4) NK_GEMM_CASE(4, 2, 4, 2) NK_GEMM_CASE(1, 2, 1, 2)
-    NK_GEMM_CASE(4, 6, 2, 2) NK_GEMM_CASE(2, 5, 2, 1)
-    NK_FAIL(NK_ERR_UNSUPPORTED, "dW GEMM: no kernel for %d x %d tiles", MT, NT);
+        if (MT == MT_ && NT == NT_) { \
+            NK_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_gemm<MT_, NT_, WM_, WN_>, \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+            hipLaunchKernelGGL((k_dw_gemm<MT_, NT_, WM_, WN_>), grid, block, lds_bytes, stream, batch); \
+        } else
+        // width 256: trunk / feature, trunk 0, rgb, alpha, skip (h + gamma(x)), views (feat + gamma(d))
+        NK_GEMM_CASE(8, 8, 2, 4) NK_GEMM_CASE(8, 2, 4, 2) NK_GEMM_CASE(1, 4, 1, 4) NK_GEMM_CASE(1, 8, 1, 8)
+        NK_GEMM_CASE(8, 10, 4, 2) NK_GEMM_CASE(4, 9, 2, 3)
+        // width 128: the same six ((1, 4) doubles as its alpha shape)
+        NK_GEMM_CASE(4, 4, 2, 4) NK_GEMM_CASE(4, 2, 4, 2) NK_GEMM_CASE(1, 2, 1, 2)
+        NK_GEMM_CASE(4, 6, 2, 2) NK_GEMM_CASE(2, 5, 2, 1)
+        NK_FAIL(NK_ERR_UNSUPPORTED, "dW GEMM: no kernel for %d x %d tiles", MT, NT);
 #undef NK_GEMM_CASE
-    NK_CHECK_LAUNCH("k_dw_gemm");
+        NK_CHECK_LAUNCH("k_dw_gemm");
+    }
     return NK_OK;
 }
 
@@ -327,30 +357,27 @@ extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const vo
     const NkLayer& lfeat = p.layer[D + 1];
     const NkLayer& lalpha = p.layer[D];
     const int pex0 = 3 + 6 * p.Lx;          // width of gamma(x) inside a skip layer's input
+    GemmQueue q;
     {   // rgb: rows 0..2 of dOut against g
         GemmDst d[2][2] = {};
         d[0][0] = gemm_dst(lrgb.w_off, lrgb.in_dim, 0, 3, NK_COL_IDENT, 0, WD, 0);
-        rc = launch_gemm(dz(0), 32, nullptr, 0, act(3 + D), WD, nullptr, 0, G, grad, d, lrgb.b_off, -1, st);
-        if (rc < 0) return rc;
+        queue_gemm(q, dz(0), 32, nullptr, 0, act(3 + D), WD, nullptr, 0, G, grad, d, lrgb.b_off, -1);
     }
     {   // views: dZ_views against cat[feat, gamma(d)]
         GemmDst d[2][2] = {};
         d[0][0] = gemm_dst(lviews.w_off, lviews.in_dim, 0, WD, NK_COL_IDENT, 0, W, 0);
         d[0][1] = gemm_dst(lviews.w_off, lviews.in_dim, 0, WD, NK_COL_PED, W, 32, p.Ld);
-        rc = launch_gemm(dz(1), WD, nullptr, 0, act(2 + D), W, act(1), 32, G, grad, d, lviews.b_off, -1, st);
-        if (rc < 0) return rc;
+        queue_gemm(q, dz(1), WD, nullptr, 0, act(2 + D), W, act(1), 32, G, grad, d, lviews.b_off, -1);
     }
     {   // alpha: row 3 of dOut against h_{D-1}
         GemmDst d[2][2] = {};
         d[0][0] = gemm_dst(lalpha.w_off, lalpha.in_dim, 3, 1, NK_COL_IDENT, 0, W, 0);
-        rc = launch_gemm(dz(0), 32, nullptr, 0, act(2 + D - 1), W, nullptr, 0, G, grad, d, lalpha.b_off, -1, st);
-        if (rc < 0) return rc;
+        queue_gemm(q, dz(0), 32, nullptr, 0, act(2 + D - 1), W, nullptr, 0, G, grad, d, lalpha.b_off, -1);
     }
     {   // feature layer: dZ_feat against h_{D-1}
         GemmDst d[2][2] = {};
         d[0][0] = gemm_dst(lfeat.w_off, lfeat.in_dim, 0, W, NK_COL_IDENT, 0, W, 0);
-        rc = launch_gemm(dz(2), W, nullptr, 0, act(2 + D - 1), W, nullptr, 0, G, grad, d, lfeat.b_off, -1, st);
-        if (rc < 0) return rc;
+        queue_gemm(q, dz(2), W, nullptr, 0, act(2 + D - 1), W, nullptr, 0, G, grad, d, lfeat.b_off, -1);
     }
     for (int L = D - 1; L >= 0; --L) {     // trunk
         const NkLayer& l = p.layer[L];
@@ -358,16 +385,15 @@ extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const vo
         GemmDst d[2][2] = {};
         if (L == 0) {
             d[0][0] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_PEX, 0, 64, p.Lx);
-            rc = launch_gemm(dzl, W, nullptr, 0, act(0), 64, nullptr, 0, G, grad, d, l.b_off, -1, st);
+            queue_gemm(q, dzl, W, nullptr, 0, act(0), 64, nullptr, 0, G, grad, d, l.b_off, -1);
         } else if (p.skip >= 0 && L == p.skip + 1) {
             d[0][0] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_IDENT, pex0, W, 0);
             d[0][1] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_PEX, 0, 64, p.Lx);
-            rc = launch_gemm(dzl, W, nullptr, 0, act(2 + L - 1), W, act(0), 64, G, grad, d, l.b_off, -1, st);
+            queue_gemm(q, dzl, W, nullptr, 0, act(2 + L - 1), W, act(0), 64, G, grad, d, l.b_off, -1);
         } else {
             d[0][0] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_IDENT, 0, W, 0);
-            rc = launch_gemm(dzl, W, nullptr, 0, act(2 + L - 1), W, nullptr, 0, G, grad, d, l.b_off, -1, st);
+            queue_gemm(q, dzl, W, nullptr, 0, act(2 + L - 1), W, nullptr, 0, G, grad, d, l.b_off, -1);
         }
-        if (rc < 0) return rc;
     }
-    return NK_OK;
+    return flush_gemms(q, st);
 }
