@@ -209,3 +209,37 @@ def test_run_nerf_cli_trains_saves_resumes_and_renders(nk, tmp_path):
     r = run("--load-checkpoint", str(out / "checkpoint00049.ckpt"), "--render-only", "--render-poses", str(path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rendered 4 frames" in r.stdout
+
+
+def test_wheel_capture_end_to_end(nk, tmp_path):
+    """The reference's own robot capture through the whole chain: poses.txt -> transforms.json
+    (converter), robot loader (8x down-sampling, every 8th frame held out, NDC rays), the
+    wheel experiment shape (4x128, L = 6, 64 + 64 samples) trained for 300 iterations through
+    the command line.  The loss on the photographs must fall well below its starting value."""
+    import shutil
+    import yaml
+    cap = tmp_path / "capture"
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "wheel_real_robot"), cap)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "nerf_kinematics_amd.poses", "--poses", str(cap / "poses.txt"),
+                        "--image_folder", str(cap / "images_robot"), "--recenter", "--output", str(cap / "transforms.json")],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with open(os.path.join(ROOT, "configs", "wheel_robot.yml")) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg["dataset"]["basedir"] = str(cap)
+    cfg["experiment"].update(id="wheel", logdir=str(tmp_path), train_iters=300, print_every=50, validate_every=150,
+                             save_every=1000)
+    p = tmp_path / "wheel.yml"
+    p.write_text(yaml.safe_dump(cfg))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_nerf.py"), "--config", str(p)], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    recs = [json.loads(l) for l in (tmp_path / "wheel" / "log.jsonl").read_text().splitlines()]
+    train = [x["train"] for x in recs if "train" in x]
+    val = [x["validation"] for x in recs if "validation" in x]
+    print("wheel losses", [round(t["loss"], 4) for t in train], "val", [(v["view"], round(v["psnr"], 2)) for v in val])
+    assert all(math.isfinite(t["loss"]) for t in train)
+    assert train[-1]["loss"] < 0.5 * train[0]["loss"]
+    assert val and all(v["view"] in (0, 8) for v in val)          # the held-out frames
+    assert (tmp_path / "wheel" / "checkpoint00299.ckpt").is_file()
