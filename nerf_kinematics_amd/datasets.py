@@ -225,7 +225,7 @@ def load_transforms(path: str, downsample: int = 1, near: float = 2.0, far: floa
     n = len(frames)
     if holdout > 0:
         i_test = np.arange(n)[::holdout]
-        i_train = np.array([i for i in range(n) if i not in set(i_test.tolist())], dtype=np.int64)
+        i_train = np.setdiff1d(np.arange(n), i_test)
         i_val = i_test
     else:
         i_train, i_val = np.arange(n_main), np.arange(n_main, n)
