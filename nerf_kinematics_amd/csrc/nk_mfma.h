@@ -74,9 +74,25 @@ struct WStream {
     int wave, lane;
     NK_D void issue_next(int nb) {       // nb = 1-KiB blocks of the stage after next (0: none left)
         char* dst = ring + nxt * slot_bytes;
+#ifndef NK_DMA_ASM
+#define NK_DMA_ASM 1
+#endif
+#if NK_DMA_ASM
+        // Issued from asm: hipcc books a global_load ... lds as a pending FLAT operation, and while
+        // one is pending (it never sees the hand-written vmcnt waits) it turns every counted
+        // lgkmcnt wait of the tile's LDS reads into lgkmcnt(0).
+        const uint32_t voff = lane * 16;
+        for (int b = wave; b < nb; b += NW) {
+            const uint32_t l = (uint32_t)(uintptr_t)(NK_LDS char*)(dst + b * 1024);
+            const char* sb = g + (int64_t)b * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(l), "v"(voff), "s"(sb) : "memory");     // (m0 is reserved: hipcc sets it itself before each use)
+        }
+#else
         for (int b = wave; b < nb; b += NW)
             __builtin_amdgcn_global_load_lds((const NK_GLB void*)(g + (int64_t)b * 1024 + lane * 16),
                                              (NK_LDS void*)(dst + b * 1024), 16, 0, 0);
+#endif
         g += (int64_t)nb * 1024;
         nxt = nxt == 2 ? 0 : nxt + 1;
     }
