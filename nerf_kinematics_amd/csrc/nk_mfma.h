@@ -204,6 +204,16 @@ NK_D void save_tile(char* dst, int64_t grp, int NO, int t, int c, int h, const F
 
 NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1);
 
+// max(x, 0) as ONE instruction, v_max_i32 on the bit pattern (negative floats are negative
+// integers; -0 and NaNs with the sign bit set give +0, other NaNs pass).  fmaxf() costs two:
+// hipcc first canonicalises x with v_max_f32 x, x, also behind __builtin_amdgcn_fmed3f; inline asm
+// is no way out either, the hazard recogniser does not cover an asm operand read straight after
+// the MFMA that wrote it.
+NK_D float relu1(float x) {
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
+
 // Accumulator tile -> bf16 fragments (ReLU when `relu`), shifting the SIGN bit of each
 // pre-activation into `mw`, one v_alignbit per register (first register ends up highest).
 // The forward kernel stores ~mw for a ReLU layer (all ones otherwise) as the layer's
@@ -229,7 +239,7 @@ NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         float x0 = a[2 * w], x1 = a[2 * w + 1], y0 = a[8 + 2 * w], y1 = a[8 + 2 * w + 1];
-        if (relu) { x0 = fmaxf(x0, 0.0f); x1 = fmaxf(x1, 0.0f); y0 = fmaxf(y0, 0.0f); y1 = fmaxf(y1, 0.0f); }
+        if (relu) { x0 = relu1(x0); x1 = relu1(x1); y0 = relu1(y0); y1 = relu1(y1); }
         f0.u[w] = pack_bf16(x0, x1);
         f1.u[w] = pack_bf16(y0, y1);
     }
