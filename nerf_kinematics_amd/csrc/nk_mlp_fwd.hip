@@ -133,7 +133,6 @@ struct FwdArgs {
 };
 
 #include "nk_fwd_chain.inc"
-#include "nk_fwd_chain_pp.inc"
 
 
 extern "C" int64_t nk_act_bytes(const nk_arch* arch, int64_t R, int32_t n) {
@@ -162,11 +161,8 @@ extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const flo
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
     const bool save = act_save != nullptr;
 #define NK_FWD_LAUNCH(W_, WD_, NW_, LDS_) do { \
-        if (NW_ == 8) { \
-            if (save) hipLaunchKernelGGL((k_mlp_fwd_pp<W_, WD_, true>), grid, block, LDS_, nk_stream(stream), a); \
-            else hipLaunchKernelGGL((k_mlp_fwd_pp<W_, WD_, false>), grid, block, LDS_, nk_stream(stream), a); \
-        } else if (save) hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, 4, true>), grid, block, LDS_, nk_stream(stream), a); \
-        else hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, 4, false>), grid, block, LDS_, nk_stream(stream), a); } while (0)
+        if (save) hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, true>), grid, block, LDS_, nk_stream(stream), a); \
+        else hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, false>), grid, block, LDS_, nk_stream(stream), a); } while (0)
     if (a.plan.W == 256) {
         constexpr int lds_bytes = 3 * (16 + 4 + 1) * 1024;     // three ring slots
         if (nw == 8) NK_FWD_LAUNCH(256, 128, 8, lds_bytes); else NK_FWD_LAUNCH(256, 128, 4, lds_bytes);
