@@ -150,5 +150,7 @@ int nk_build_plan(const nk_arch* arch, NkPlan* plan);   // host; returns nk_stat
 static inline hipStream_t nk_stream(void* s) { return (hipStream_t)s; }
 
 // Wavefronts per workgroup of the MLP chain kernels (4: two workgroups share a CU and run out of
-// phase; 8: one workgroup per CU streams the weights once for 256 points).  NK_WAVES overrides.
-int nk_waves_per_wg();
+// phase; 8: one workgroup per CU streams the weights once for 256 points), for the forward
+// (backward = 0) or the backward chain.  NK_WAVES / NK_WAVES_FWD / NK_WAVES_BWD override.
+#define NK_WAVES_BWD_DEFAULT 8
+int nk_waves_per_wg(int backward);

@@ -336,7 +336,7 @@ extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const vo
     a.act = (const char*)act_save; a.d_raw = d_raw; a.dz = (char*)dz_scratch;
     a.P = R * (int64_t)n; a.G = nk_groups(a.P);
     hipStream_t st = nk_stream(stream);
-    const int nw = nk_waves_per_wg();
+    const int nw = nk_waves_per_wg(1);
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
     if (p.W == 256) {
         if (nw == 8) hipLaunchKernelGGL((k_mlp_bwd<256, 128, 8>), grid, block, 3 * (16 + 1) * 1024, st, a);

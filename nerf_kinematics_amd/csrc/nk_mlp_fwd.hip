@@ -157,7 +157,7 @@ extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const flo
 #ifdef NK_STAMPS
     { const char* e = getenv("NK_STAMP_PTR"); a.stamps = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
-    const int nw = nk_waves_per_wg();
+    const int nw = nk_waves_per_wg(0);
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
     const bool save = act_save != nullptr;
 #define NK_FWD_LAUNCH(W_, WD_, NW_, LDS_) do { \

@@ -17,13 +17,19 @@ void nk_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-int nk_waves_per_wg() {
-    static int nw = 0;
-    if (nw == 0) {
+int nk_waves_per_wg(int backward) {
+    static int nw[2] = {0, 0};
+    if (nw[0] == 0) {
+        // NK_WAVES=4|8 sets both kernels, NK_WAVES_FWD / NK_WAVES_BWD one of them
         const char* e = getenv("NK_WAVES");
-        nw = (e && atoi(e) == 8) ? 8 : 4;
+        const char* ef = getenv("NK_WAVES_FWD");
+        const char* eb = getenv("NK_WAVES_BWD");
+        const int all = e ? atoi(e) : 0;
+        const int f = ef ? atoi(ef) : all, b = eb ? atoi(eb) : all;
+        nw[1] = (b == 4) ? 4 : ((b == 8) ? 8 : NK_WAVES_BWD_DEFAULT);
+        nw[0] = (f == 8) ? 8 : 4;
     }
-    return nw;
+    return nw[backward ? 1 : 0];
 }
 
 extern "C" const char* nk_last_error(void) { return g_err; }
