@@ -155,3 +155,21 @@ def test_adam_kernel_matches_torch_adam(nk, dev):
     st = opt.state[ref]
     np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-6, atol=3e-8)
     np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-10)
+
+
+def test_other_workgroup_sizes_in_a_child_process(nk):
+    """The chain kernels are built for 4 and 8 wavefronts per workgroup; the library reads the choice
+    from the environment once per process, so the non-default pair (forward 8, backward 4) is checked
+    by running the MLP parity tests again in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NK_WAVES_FWD="8", NK_WAVES_BWD="4")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_gpu_backward.py"), os.path.join(here, "test_gpu_parity.py"),
+                        "-k", "mlp_backward_matches_autograd or render_rays_gradients or mlp_forward"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "mlp_forward" not in r.stderr
+    n = int(r.stdout.strip().splitlines()[-1].split(" passed")[0].split()[-1])
+    assert n >= 9, r.stdout[-500:]        # 3 + 2 backward cases, 4 forward cases
