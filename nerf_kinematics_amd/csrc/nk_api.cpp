@@ -8,8 +8,10 @@
 namespace {
 
 struct WsLayout {
-    int64_t z_c, raw_c, w_c, rgb_c_tmp, z_all, raw_f, act_c, act_f, d_raw, dz, total;
+    int64_t z_c, raw_c, w_c, rgb_c_tmp, z_all, raw_f, act_c, act_f, d_raw, dz, dz_c, total;
 };
+
+constexpr int64_t NK_PAIR_GEMM_MAX_POINTS = 1 << 20;
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -24,7 +26,7 @@ int layout(const nk_arch* ac, const nk_arch* af, const nk_render_opts* o, int64_
     L->raw_c = take(R * Nc * 16);
     L->w_c = take(R * Nc * 4);
     L->rgb_c_tmp = take(R * 12);
-    L->z_all = L->raw_f = L->act_c = L->act_f = L->d_raw = L->dz = -1;
+    L->z_all = L->raw_f = L->act_c = L->act_f = L->d_raw = L->dz = L->dz_c = -1;
     if (Nf > 0) { L->z_all = take(R * N * 4); L->raw_f = take(R * N * 16); }
     if (training) {
         int64_t b = nk_act_bytes(ac, R, Nc);
@@ -42,6 +44,10 @@ int layout(const nk_arch* ac, const nk_arch* af, const nk_render_opts* o, int64_
         }
         L->d_raw = take(R * (Nf > 0 ? N : Nc) * 16);
         L->dz = take(dzb);
+        // Small batches: the coarse network gets a dZ region of its own, so that the weight-gradient
+        // GEMMs of both networks can run in shared launches after both chains (one network's
+        // products alone leave most of the chip idle).  Large batches reuse one region in turn.
+        if (Nf > 0 && R * (int64_t)N <= NK_PAIR_GEMM_MAX_POINTS) L->dz_c = take(nk_dz_bytes(ac, R, Nc));
     }
     L->total = off;
     return NK_OK;
@@ -100,17 +106,28 @@ extern "C" int nk_render_rays_bwd(const nk_arch* ac, const void* pc, const nk_ar
     const int Nc = o->num_coarse, Nf = o->num_fine, N = Nc + Nf;
     char* ws = (char*)workspace;
     float* d_raw = (float*)(ws + L.d_raw);
-    if (Nf > 0 && d_rgb_fine) {
-        if (!pf || !grad_fine) NK_FAIL(NK_ERR_ARG, "nk_render_rays_bwd: fine gradient requested without packed_fine / grad_fine");
+    hipStream_t st = nk_stream(stream);
+    const bool fine = Nf > 0 && d_rgb_fine, coarse = d_rgb_coarse != nullptr;
+    if (fine && (!pf || !grad_fine)) NK_FAIL(NK_ERR_ARG, "nk_render_rays_bwd: fine gradient requested without packed_fine / grad_fine");
+    if (coarse && !grad_coarse) NK_FAIL(NK_ERR_ARG, "nk_render_rays_bwd: coarse gradient requested without grad_coarse");
+    const NkBwdJob jf = {af, pf, ws + L.act_f, d_raw, R, N, ws + L.dz, grad_fine};
+    const NkBwdJob jc = {ac, pc, ws + L.act_c, d_raw, R, Nc, ws + (L.dz_c >= 0 ? L.dz_c : L.dz), grad_coarse};
+    const bool together = fine && coarse && L.dz_c >= 0;
+    if (fine) {
         if ((rc = nk_raw2outputs_bwd((float*)(ws + L.raw_f), (float*)(ws + L.z_all), ray_batch, R, N, o,
                                      NK_STREAM_NOISE_FINE, d_rgb_fine, nullptr, nullptr, d_raw, stream)) < 0) return rc;
-        if ((rc = nk_mlp_backward(af, pf, ws + L.act_f, d_raw, R, N, ws + L.dz, grad_fine, stream)) < 0) return rc;
+        if ((rc = nk_mlp_backward_chain(jf, st)) < 0) return rc;
+        if (!together && (rc = nk_mlp_backward_gemms(&jf, 1, st)) < 0) return rc;
     }
-    if (d_rgb_coarse) {
-        if (!grad_coarse) NK_FAIL(NK_ERR_ARG, "nk_render_rays_bwd: coarse gradient requested without grad_coarse");
+    if (coarse) {
         if ((rc = nk_raw2outputs_bwd((float*)(ws + L.raw_c), (float*)(ws + L.z_c), ray_batch, R, Nc, o,
                                      NK_STREAM_NOISE_COARSE, d_rgb_coarse, nullptr, nullptr, d_raw, stream)) < 0) return rc;
-        if ((rc = nk_mlp_backward(ac, pc, ws + L.act_c, d_raw, R, Nc, ws + L.dz, grad_coarse, stream)) < 0) return rc;
+        if ((rc = nk_mlp_backward_chain(jc, st)) < 0) return rc;
+        if (!together && (rc = nk_mlp_backward_gemms(&jc, 1, st)) < 0) return rc;
+    }
+    if (together) {
+        const NkBwdJob both[2] = {jf, jc};
+        if ((rc = nk_mlp_backward_gemms(both, 2, st)) < 0) return rc;
     }
     return NK_OK;
 }

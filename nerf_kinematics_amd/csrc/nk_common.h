@@ -154,3 +154,12 @@ static inline hipStream_t nk_stream(void* s) { return (hipStream_t)s; }
 // (backward = 0) or the backward chain.  NK_WAVES / NK_WAVES_FWD / NK_WAVES_BWD override.
 #define NK_WAVES_BWD_DEFAULT 8
 int nk_waves_per_wg(int backward);
+
+// The two halves of nk_mlp_backward, for callers that run the chains of two networks first and
+// then all weight-gradient GEMMs together (nk_render_rays_bwd on small batches).
+struct NkBwdJob {
+    const nk_arch* arch; const void* packed; const void* act; const float* d_raw;
+    int64_t R; int32_t n; void* dz; float* grad;
+};
+int nk_mlp_backward_chain(const NkBwdJob& job, hipStream_t stream);
+int nk_mlp_backward_gemms(const NkBwdJob* jobs, int count, hipStream_t stream);

@@ -252,8 +252,8 @@ static GemmDst gemm_dst(int w_off, int ld, int row_first, int row_count, int col
 
 // Products queued by nk_mlp_backward, launched shape by shape.
 struct GemmQueue {
-    GemmArgs g[16];
-    int MT[16], NT[16];
+    GemmArgs g[32];         // 12 products per network, two networks
+    int MT[32], NT[32];
     int n = 0;
 };
 
@@ -281,7 +281,7 @@ static void queue_gemm(GemmQueue& q, const char* A0, int wA0, const char* A1, in
 }
 
 static int flush_gemms(GemmQueue& q, hipStream_t stream) {
-    bool done[16] = {};
+    bool done[32] = {};
     for (int first = 0; first < q.n; ++first) {
         if (done[first]) continue;
         const int MT = q.MT[first], NT = q.NT[first];
@@ -290,8 +290,12 @@ static int flush_gemms(GemmQueue& q, hipStream_t stream) {
         for (int k = first; k < q.n && count < NK_GEMM_BATCH; ++k)
             if (!done[k] && q.MT[k] == MT && q.NT[k] == NT) { batch.g[count++] = q.g[k]; done[k] = true; }
         for (int k = count; k < NK_GEMM_BATCH; ++k) batch.g[k] = batch.g[0];
-        const GemmArgs& g = batch.g[0];
-        const unsigned nwg = (unsigned)((g.n_stages + g.stages_per_wg - 1) / g.stages_per_wg);
+        unsigned nwg = 1;        // products of two networks differ in length: the longest sets the grid
+        for (int k = 0; k < count; ++k) {
+            const GemmArgs& g = batch.g[k];
+            const unsigned n = (unsigned)((g.n_stages + g.stages_per_wg - 1) / g.stages_per_wg);
+            if (n > nwg) nwg = n;
+        }
         const int lds_bytes = NK_GEMM_RING * (MT + NT) * 2048;
         const dim3 grid(nwg, count), block(512);
         // (A tiles, B tiles) -> wave grid; every shape the supported networks produce
@@ -322,20 +326,19 @@ extern "C" int64_t nk_dz_bytes(const nk_arch* arch, int64_t R, int32_t n) {
     return nk_dz_offset(p, nk_dz_count(p), nk_groups(R * (int64_t)n));
 }
 
-extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const void* act_save, const float* d_raw,
-                               int64_t R, int32_t n, void* dz_scratch, float* grad, void* stream) {
-    if (!packed || !act_save || !d_raw || !dz_scratch || !grad || R <= 0 || n <= 0)
+// dZ chain of one network: d_raw -> dZ of every layer (bf16, into job.dz)
+int nk_mlp_backward_chain(const NkBwdJob& j, hipStream_t st) {
+    if (!j.packed || !j.act || !j.d_raw || !j.dz || !j.grad || j.R <= 0 || j.n <= 0)
         NK_FAIL(NK_ERR_ARG, "nk_mlp_backward: null pointer or non-positive size");
-    if (((uintptr_t)packed & 15) || ((uintptr_t)act_save & 15) || ((uintptr_t)dz_scratch & 15) || ((uintptr_t)d_raw & 15))
+    if (((uintptr_t)j.packed & 15) || ((uintptr_t)j.act & 15) || ((uintptr_t)j.dz & 15) || ((uintptr_t)j.d_raw & 15))
         NK_FAIL(NK_ERR_ARG, "nk_mlp_backward: buffers must be 16-byte aligned");
     BwdArgs a;
-    int rc = nk_build_plan(arch, &a.plan);
+    int rc = nk_build_plan(j.arch, &a.plan);
     if (rc < 0) return rc;
     const NkPlan& p = a.plan;
-    a.packed_t = (const char*)packed + (int64_t)p.fwd_blocks * 1024;
-    a.act = (const char*)act_save; a.d_raw = d_raw; a.dz = (char*)dz_scratch;
-    a.P = R * (int64_t)n; a.G = nk_groups(a.P);
-    hipStream_t st = nk_stream(stream);
+    a.packed_t = (const char*)j.packed + (int64_t)p.fwd_blocks * 1024;
+    a.act = (const char*)j.act; a.d_raw = j.d_raw; a.dz = (char*)j.dz;
+    a.P = j.R * (int64_t)j.n; a.G = nk_groups(a.P);
     const int nw = nk_waves_per_wg(1);
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
     if (p.W == 256) {
@@ -346,18 +349,25 @@ extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const vo
         else hipLaunchKernelGGL((k_mlp_bwd<128, 64, 4>), grid, block, 3 * (8 + 1) * 1024, st, a);
     }
     NK_CHECK_LAUNCH("k_mlp_bwd");
+    return NK_OK;
+}
 
-    // weight / bias gradients: one GEMM per dZ tensor, with operands that two layers share read once
+// weight / bias gradients of one network: one GEMM per dZ tensor, with operands that two layers
+// share read once
+static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
+    NkPlan p;
+    int rc = nk_build_plan(j.arch, &p);
+    if (rc < 0) return rc;
     const int D = p.D, W = p.W, WD = p.WD;
-    const int64_t G = a.G;
-    auto act = [&](int idx) { return a.act + nk_act_offset(p, idx, G); };
-    auto dz = [&](int idx) { return (const char*)a.dz + nk_dz_offset(p, idx, G); };
+    const int64_t G = nk_groups(j.R * (int64_t)j.n);
+    float* grad = j.grad;
+    auto act = [&](int idx) { return (const char*)j.act + nk_act_offset(p, idx, G); };
+    auto dz = [&](int idx) { return (const char*)j.dz + nk_dz_offset(p, idx, G); };
     const NkLayer& lrgb = p.layer[D + 3];
     const NkLayer& lviews = p.layer[D + 2];
     const NkLayer& lfeat = p.layer[D + 1];
     const NkLayer& lalpha = p.layer[D];
     const int pex0 = 3 + 6 * p.Lx;          // width of gamma(x) inside a skip layer's input
-    GemmQueue q;
     {   // rgb: rows 0..2 of dOut against g
         GemmDst d[2][2] = {};
         d[0][0] = gemm_dst(lrgb.w_off, lrgb.in_dim, 0, 3, NK_COL_IDENT, 0, WD, 0);
@@ -395,5 +405,25 @@ extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const vo
             queue_gemm(q, dzl, W, nullptr, 0, act(2 + L - 1), W, nullptr, 0, G, grad, d, l.b_off, -1);
         }
     }
+    return NK_OK;
+}
+
+// GEMMs of one or two networks whose chains have run; products of equal shape share a launch,
+// across the networks too (what fills the chip when a training batch is small)
+int nk_mlp_backward_gemms(const NkBwdJob* jobs, int count, hipStream_t st) {
+    if (count < 1 || count > 2) NK_FAIL(NK_ERR_ARG, "nk_mlp_backward_gemms: %d networks", count);
+    GemmQueue q;
+    for (int k = 0; k < count; ++k) {
+        int rc = queue_network_gemms(q, jobs[k]);
+        if (rc < 0) return rc;
+    }
     return flush_gemms(q, st);
+}
+
+extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const void* act_save, const float* d_raw,
+                               int64_t R, int32_t n, void* dz_scratch, float* grad, void* stream) {
+    const NkBwdJob j = {arch, packed, act_save, d_raw, R, n, dz_scratch, grad};
+    int rc = nk_mlp_backward_chain(j, nk_stream(stream));
+    if (rc < 0) return rc;
+    return nk_mlp_backward_gemms(&j, 1, nk_stream(stream));
 }
