@@ -269,10 +269,14 @@ static void queue_gemm(GemmQueue& q, const char* A0, int wA0, const char* A1, in
         for (int j = 0; j < 2; ++j) g.dst[i][j] = dst[i][j];
     g.b_off[0] = b_off0; g.b_off[1] = b_off1;
     g.n_stages = G;
-    // Split-K width: one workgroup per CU for large batches; fewer when a workgroup would see less
-    // than ~48 stages, because every workgroup pays the same atomic epilogue (one output matrix).
+    // Split-K width: one workgroup per CU for large batches; fewer when a workgroup would see too
+    // few stages, because every workgroup pays the same atomic epilogue (one output matrix): at
+    // least 3 stages per output tile, between 8 and 48.
     static const int env_wgs = []() { const char* e = getenv("NK_GEMM_WGS"); return e ? atoi(e) : 0; }();
-    int64_t target_wgs = env_wgs > 0 ? env_wgs : g.n_stages / 48;
+    static const int env_k = []() { const char* e = getenv("NK_GEMM_STAGES_PER_TILE"); return e ? atoi(e) : 3; }();
+    int min_stages = env_k * q.MT[q.n] * q.NT[q.n];
+    min_stages = min_stages < 8 ? 8 : (min_stages > 48 ? 48 : min_stages);
+    int64_t target_wgs = env_wgs > 0 ? env_wgs : g.n_stages / min_stages;
     if (env_wgs <= 0) target_wgs = target_wgs < 64 ? 64 : (target_wgs > 256 ? 256 : target_wgs);
     g.stages_per_wg = (g.n_stages + target_wgs - 1) / target_wgs;
     if (g.stages_per_wg < 1) g.stages_per_wg = 1;
