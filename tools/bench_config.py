@@ -4,6 +4,9 @@ and rays per step of the YAML, on the synthetic teacher scene.
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from nerf_kinematics_amd import lib as _L
+if os.environ.get("NK_LIB"):            # experiment builds
+    _L.LIB_PATH = os.path.abspath(os.environ["NK_LIB"])
 from nerf_kinematics_amd import config as C
 from nerf_kinematics_amd.datasets import RaySampler, teacher_scene
 from nerf_kinematics_amd.model import Arch, ARCH_LEGO_CKPT, ARCH_WHEEL_CKPT
