@@ -3,7 +3,7 @@ import sys, os, math, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nerf_kinematics_amd import lib as L_
-if os.environ.get("NK_LIB"):            # experiment builds (tools/bin/*.so)
+if os.environ.get("NK_LIB"):            # experiment builds (tools/ab/*.so)
     L_.LIB_PATH = os.path.abspath(os.environ["NK_LIB"])
 import nerf_kinematics_amd as nk
 
