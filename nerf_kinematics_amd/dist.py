@@ -19,8 +19,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:     # NK_DIST_BACKEND=gloo: several ranks sharing one GPU (tests); RCCL wants one GPU per rank
+            backend = os.environ.get("NK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": torch.device(f"cuda:{local}")} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
@@ -29,6 +29,31 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
 def shard_rows(n: int, rank: int, world: int) -> slice:
     """Rows rank::world of a common batch (used by the 1-vs-N gradient equality test)."""
     return slice(rank, n, world)
+
+
+def row_block(n: int, rank: int, world: int) -> slice:
+    """The contiguous block of rows rank takes when n rows are rendered by `world` ranks (the last
+    blocks may be shorter or empty)."""
+    per = (n + world - 1) // world
+    return slice(min(rank * per, n), min((rank + 1) * per, n))
+
+
+def gather_rows(local: torch.Tensor, n: int, group=None) -> torch.Tensor:
+    """Concatenate the row blocks of every rank (split as row_block does) on every rank: one
+    all-gather of equally padded blocks, no other exchange.  Whole-image renders shard this way:
+    rays are independent, so the hot loop needs no collective at all."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    per = (n + world - 1) // world
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    on_cpu = dist.get_backend(group) == "gloo" and pad.is_cuda       # gloo gathers host tensors
+    src = pad.cpu() if on_cpu else pad
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    out = torch.cat(parts)[:n]
+    return out.to(local.device) if on_cpu else out
 
 
 def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:

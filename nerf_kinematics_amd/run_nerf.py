@@ -10,7 +10,8 @@ Scalars go to ``<logdir>/<id>/log.jsonl`` (one JSON object per line) instead of 
 files.
 
 One process per GPU: under ``torch.distributed.run`` every rank draws its own rays and the flat
-gradient is all-reduced (RCCL); rank 0 validates, logs and saves.
+gradient is all-reduced (RCCL); whole-image renders are sharded by rows and all-gathered; rank 0
+logs and saves.
 """
 from __future__ import annotations
 
@@ -68,7 +69,7 @@ def render_view(tr: Trainer, scene: Scene, cfg: dict, k: Optional[int] = None, p
     kw = config_mod.render_kwargs(cfg, "validation")
     chunk = int(cfg["nerf"]["validation"].get("chunksize", 131072))
     rb = scene.rays(0 if k is None else k, tr.device, pose=pose)
-    out = tr.render(rb, chunk=max(1024, min(chunk, 65536)), opts=kw)
+    out = tr.render(rb, chunk=max(1024, min(chunk, 65536)), opts=kw, shard=True)    # every rank takes a block of rows
     return out["rgb_fine"].view(scene.H, scene.W, 3)
 
 
@@ -80,10 +81,12 @@ def validate(tr: Trainer, scene: Scene, cfg: dict, k: int):
     return mse, mse2psnr(mse), p8, img
 
 
-def render_path(tr: Trainer, scene: Scene, cfg: dict, poses_json: str, outdir: str) -> int:
+def render_path(tr: Trainer, scene: Scene, cfg: dict, poses_json: str, outdir: str, write: bool = True) -> int:
     """Render every frame of a transforms json (keys ``transform_matrix`` or
-    ``transform_matrix_start``, as the pose converter writes for its test / video rings)."""
-    os.makedirs(outdir, exist_ok=True)
+    ``transform_matrix_start``, as the pose converter writes for its test / video rings).  Called
+    by every rank (each renders its rows of every frame); ``write`` is true on the rank that saves."""
+    if write:
+        os.makedirs(outdir, exist_ok=True)
     frames = read_transforms(poses_json)["frames"]
     n = 0
     for i, fr in enumerate(frames):
@@ -91,7 +94,8 @@ def render_path(tr: Trainer, scene: Scene, cfg: dict, poses_json: str, outdir: s
         if m is None:
             continue
         img = render_view(tr, scene, cfg, pose=np.array(m, dtype=np.float32))
-        save_png(os.path.join(outdir, f"{i:04d}.png"), to_8bit(img.cpu().numpy()))
+        if write:
+            save_png(os.path.join(outdir, f"{i:04d}.png"), to_8bit(img.cpu().numpy()))
         n += 1
     return n
 
@@ -126,19 +130,21 @@ def main(argv=None) -> int:
             print(f"resumed {a.load_checkpoint} at iteration {tr.iteration}", flush=True)
     scene = load_scene(cfg, dev)
 
-    if a.render_only:
-        if rank == 0:
-            out = os.path.join(logdir, "render")
-            if a.render_poses:
-                n = render_path(tr, scene, cfg, a.render_poses, out)
-            else:
+    if a.render_only:           # every rank renders its block of rows of every frame; rank 0 writes
+        out = os.path.join(logdir, "render")
+        if a.render_poses:
+            n = render_path(tr, scene, cfg, a.render_poses, out, write=rank == 0)
+        else:
+            if rank == 0:
                 os.makedirs(out, exist_ok=True)
-                n = 0
-                for k in scene.i_test:
-                    mse, psnr, p8, img = validate(tr, scene, cfg, int(k))
+            n = 0
+            for k in scene.i_test:
+                mse, psnr, p8, img = validate(tr, scene, cfg, int(k))
+                if rank == 0:
                     save_png(os.path.join(out, f"{int(k):04d}.png"), to_8bit(img.cpu().numpy()))
                     print(f"view {int(k)}: mse {mse:.6f} psnr {psnr:.3f} dB psnr8 {p8:.3f} dB", flush=True)
-                    n += 1
+                n += 1
+        if rank == 0:
             print(f"rendered {n} frames into {out}", flush=True)
         nkdist.shutdown()
         return 0
@@ -163,12 +169,13 @@ def main(argv=None) -> int:
                    "ray_samples_per_s": rate * (opts.num_coarse + opts.num_fine)}
             log.write(json.dumps({"train": rec}) + "\n"); log.flush()
             print(f"[TRAIN] Iter: {i} Loss: {loss_val:.6f} PSNR: {rec['psnr']:.3f} rays/s: {rate:.0f}", flush=True)
-        if rank == 0 and len(scene.i_val) and ((i % int(exp["validate_every"]) == 0 and i > 0) or last):
+        if len(scene.i_val) and ((i % int(exp["validate_every"]) == 0 and i > 0) or last):
             k = int(scene.i_val[(i // max(int(exp["validate_every"]), 1)) % len(scene.i_val)])
-            mse, psnr, p8, img = validate(tr, scene, cfg, k)
-            log.write(json.dumps({"validation": {"iter": i, "view": k, "loss": mse, "psnr": psnr, "psnr_8bit": p8}}) + "\n")
-            log.flush()
-            print(f"[VAL] Iter: {i} view {k} Loss: {mse:.6f} PSNR: {psnr:.3f} PSNR(8-bit): {p8:.3f}", flush=True)
+            mse, psnr, p8, img = validate(tr, scene, cfg, k)        # all ranks: the render is sharded by rows
+            if rank == 0:
+                log.write(json.dumps({"validation": {"iter": i, "view": k, "loss": mse, "psnr": psnr, "psnr_8bit": p8}}) + "\n")
+                log.flush()
+                print(f"[VAL] Iter: {i} view {k} Loss: {mse:.6f} PSNR: {psnr:.3f} PSNR(8-bit): {p8:.3f}", flush=True)
         if rank == 0 and ((i % int(exp["save_every"]) == 0 and i > 0) or last):
             lv = float(loss)
             path = os.path.join(logdir, ckpt.checkpoint_name(i))

@@ -244,10 +244,19 @@ class Trainer:
 
     # -- inference --------------------------------------------------------------------------
     @torch.no_grad()
-    def render(self, ray_batch: torch.Tensor, chunk: int = 65536, opts: Optional[dict] = None) -> Dict[str, torch.Tensor]:
-        """Whole-image render with the ``nerf.validation`` settings (no jitter, no noise)."""
+    def render(self, ray_batch: torch.Tensor, chunk: int = 65536, opts: Optional[dict] = None,
+               shard: bool = False) -> Dict[str, torch.Tensor]:
+        """Whole-image render with the ``nerf.validation`` settings (no jitter, no noise).
+
+        ``shard=True`` (every rank of the process group must call it, with the same rays): each
+        rank renders one contiguous block of the rays and the blocks are all-gathered, so every
+        rank returns the whole image."""
         from .render import render_rays
         o = self.opts
+        n_all = ray_batch.shape[0]
+        if shard and self.world > 1:
+            from . import dist as nkdist
+            ray_batch = ray_batch[nkdist.row_block(n_all, self._rank(), self.world)]
         kw = dict(num_coarse=o.num_coarse, num_fine=o.num_fine if self.fine is not None else 0, perturb=False,
                   lindisp=o.lindisp, radiance_field_noise_std=0.0, white_background=o.white_background)
         if opts:
@@ -256,7 +265,14 @@ class Trainer:
         for s in range(0, ray_batch.shape[0], chunk):
             parts.append(render_rays(ray_batch[s:s + chunk], self.coarse, self.fine, training=False, **kw))
         names = ("rgb_fine", "disp_fine", "acc_fine", "rgb_coarse", "disp_coarse", "acc_coarse")
-        return {n: torch.cat([p[i] for p in parts]) for i, n in enumerate(names)}
+        if not parts:                   # an empty block of a sharded render
+            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
+            out = {n: (z(0, 3) if n.startswith("rgb") else z(0)) for n in names}
+        else:
+            out = {n: torch.cat([p[i] for p in parts]) for i, n in enumerate(names)}
+        if shard and self.world > 1:
+            out = {n: nkdist.gather_rows(v, n_all, self.pg) for n, v in out.items()}
+        return out
 
 
 def _init_flat(arch: Arch, seed: int) -> torch.Tensor:

@@ -1,7 +1,8 @@
 """World-size-2 gloo test of the data-parallel contract (CPU; the oracle stands in for the GPU
 compute): summing per-rank gradients of the per-rank mean loss and dividing by the world size
 equals the single-process gradient on the concatenated batch, and identical updates keep the
-parameters bit-identical on every rank."""
+parameters bit-identical on every rank.  Also the row split / all-gather a sharded whole-image
+render uses."""
 import math
 import os
 import socket
@@ -57,6 +58,12 @@ def _worker(rank, world, port, q):
     m, v = torch.zeros_like(params), torch.zeros_like(params)
     O.adam_step(params, g, m, v, 1, 5e-3)
     ok = nd.params_in_sync(params)
+    # row sharding of a whole-image render: blocks of 7 rows over 2 ranks (4 + 3), and an empty block
+    full = torch.arange(21, dtype=torch.float32).view(7, 3)
+    for n in (7, 1):
+        blk = nd.row_block(n, rank, world)
+        assert torch.equal(nd.gather_rows(full[:n][blk].contiguous(), n), full[:n])
+    assert nd.row_block(7, 0, 2) == slice(0, 4) and nd.row_block(7, 1, 2) == slice(4, 7) and nd.row_block(1, 1, 2) == slice(1, 1)
     if rank == 0:
         q.put((g.numpy().copy(), ok))     # by value: the worker's shared memory dies with it
     dist.barrier()

@@ -1,6 +1,7 @@
 """Two ranks of the real Trainer (HIP path) on ONE GPU, exchanging the flat gradient over gloo:
 the data-parallel step must equal the single-process step on the concatenated batch, and every
-rank must hold bit-identical parameters afterwards.  (RCCL needs one GPU per rank; the exchange
+rank must hold bit-identical parameters afterwards; and a whole-image render sharded by rows over
+the two ranks must equal the single-process render bit for bit.  (RCCL needs one GPU per rank; the exchange
 itself is backend-independent: one all-reduce of one flat fp32 buffer.)"""
 import math
 import os
@@ -53,10 +54,12 @@ def _worker(rank, world, port, q):
     tr = _make_trainer(R // world, dev)
     assert tr.world == world
     rb, target = _batch(dev)
+    # whole-image render sharded by rows (before the step: every rank holds the same weights)
+    img = tr.render(rb[:R - 3], chunk=100, shard=True)["rgb_fine"].cpu().numpy().copy()
     sl = nd.shard_rows(R, rank, world)
     loss = float(tr.step(rb[sl].contiguous(), target[sl].contiguous()))
     in_sync = nd.params_in_sync(tr.params)
-    q.put((rank, loss, tr.grad.cpu().numpy().copy(), tr.params.cpu().numpy().copy(), in_sync))
+    q.put((rank, loss, tr.grad.cpu().numpy().copy(), tr.params.cpu().numpy().copy(), in_sync, img))
     torch.distributed.barrier()
     nd.shutdown()
 
@@ -72,14 +75,18 @@ def test_two_rank_trainer_step_equals_single_process():
         p.start()
     got = {}
     for _ in range(2):
-        rank, loss, grad, params, ok = q.get(timeout=300)
-        got[rank] = (loss, torch.from_numpy(grad), torch.from_numpy(params), ok)
+        rank, loss, grad, params, ok, img = q.get(timeout=300)
+        got[rank] = (loss, torch.from_numpy(grad), torch.from_numpy(params), ok, torch.from_numpy(img))
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
     dev = torch.device("cuda:0")
     one = _make_trainer(R, dev)
     rb, target = _batch(dev)
+    # the sharded render: every rank ends up with the whole image, bit-identical to one process's
+    img1 = one.render(rb[:R - 3], chunk=100)["rgb_fine"].cpu()
+    assert got[0][4].shape == (R - 3, 3)
+    assert torch.equal(got[0][4], img1) and torch.equal(got[1][4], img1)
     loss1 = float(one.step(rb, target))
     g1, p1 = one.grad.cpu(), one.params.cpu()
     assert float(g1.norm()) > 0

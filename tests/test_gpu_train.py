@@ -268,6 +268,54 @@ def test_run_nerf_cli_trains_saves_resumes_and_renders(nk, tmp_path):
     assert "rendered 4 frames" in r.stdout
 
 
+def test_run_nerf_cli_two_ranks(nk, tmp_path):
+    """Two ranks of the command line sharing the GPU (gloo): every rank draws its own rays, the
+    gradient is all-reduced, validation and --render-only renders are sharded by rows over both
+    ranks; rank 0 writes the log, the checkpoints and the frames."""
+    import socket
+    import yaml
+    with open(os.path.join(ROOT, "tests", "golden", "lego-lowres3_config.yml")) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg["dataset"] = {"type": "teacher", "near": 2, "far": 6, "train_views": 6, "val_views": 2, "resolution": 48}
+    cfg["experiment"].update(id="two", logdir=str(tmp_path), train_iters=30, print_every=10, validate_every=15, save_every=100)
+    cfg["nerf"]["train"]["num_random_rays"] = 512
+    p = tmp_path / "exp.yml"
+    p.write_text(yaml.safe_dump(cfg))
+
+    def run(*extra):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, PYTHONPATH=ROOT, NK_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "run_nerf.py"), "--config", str(p), *extra],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [q.communicate(timeout=400)[0] for q in procs]
+        assert all(q.returncode == 0 for q in procs), outs[0][-1500:] + outs[1][-1500:]
+        return outs
+
+    outs = run()
+    out = tmp_path / "two"
+    recs = [json.loads(l) for l in (out / "log.jsonl").read_text().splitlines()]
+    train = [r_["train"] for r_ in recs if "train" in r_]
+    val = [r_["validation"] for r_ in recs if "validation" in r_]
+    assert [t["iter"] for t in train] == [0, 10, 20, 29] and [v["iter"] for v in val] == [15, 29]
+    assert train[-1]["loss"] < train[0]["loss"] and all(math.isfinite(v["psnr_8bit"]) and v["psnr"] > 5 for v in val)
+    assert "[TRAIN]" in outs[0] and "[TRAIN]" not in outs[1]
+    ck = out / "checkpoint00029.ckpt"
+    assert ck.is_file()
+    outs = run("--load-checkpoint", str(ck), "--render-only")
+    assert "rendered 2 frames" in outs[0] and len(list((out / "render").glob("*.png"))) == 2
+    # the frames the two ranks rendered together equal a single process's
+    frames2 = {f.name: f.read_bytes() for f in (out / "render").glob("*.png")}
+    for f in (out / "render").glob("*.png"):
+        f.unlink()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_nerf.py"), "--config", str(p), "--load-checkpoint", str(ck),
+                        "--render-only"], env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert {f.name: f.read_bytes() for f in (out / "render").glob("*.png")} == frames2
+
+
 def test_wheel_capture_end_to_end(nk, tmp_path):
     """The reference's own robot capture through the whole chain: poses.txt -> transforms.json
     (converter), robot loader (8x down-sampling, every 8th frame held out, NDC rays), the
