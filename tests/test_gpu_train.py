@@ -181,6 +181,23 @@ def test_training_psnr_tracks_the_fp32_oracle(nk, dev):
     assert abs(d.mean()) < 0.25 and np.abs(d).max() < 0.6
 
 
+def test_one_call_and_staged_steps_agree(nk, dev, teacher):
+    """Trainer.step through nk_render_rays_fwd/_bwd (which, on a batch this small, runs the
+    weight-gradient GEMMs of both networks in shared launches) against the same step issued stage
+    by stage (one nk_mlp_backward per network): same loss, same gradient up to the order of the
+    fp32 atomics."""
+    from nerf_kinematics_amd.datasets import RaySampler
+    rb, tgt = RaySampler(teacher, 1024, seed=3).next(0)
+    a, b = _trainer(nk, dev, seed=11), _trainer(nk, dev, seed=11)
+    la = float(a.step(rb, tgt))
+    ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
+    lb = float(b.step(rb, tgt, events=ev))
+    assert abs(la - lb) < 1e-6 * abs(la)
+    assert float(a.grad.norm()) > 0
+    assert float((a.grad - b.grad).norm() / a.grad.norm()) < 1e-5
+    assert float((a.params - b.params).abs().max()) <= 2 * 5e-3 + 1e-6 and float((a.params - b.params).abs().mean()) < 1e-6
+
+
 def test_checkpoint_resume_continues_the_run(nk, dev, teacher, tmp_path):
     """save -> load into a fresh trainer -> the next steps follow the original run."""
     from nerf_kinematics_amd import checkpoint as ckpt
