@@ -59,7 +59,14 @@ def gather_rows(local: torch.Tensor, n: int, group=None) -> torch.Tensor:
 def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     """Sum the flat gradient over ranks in place; the Adam kernel divides by world size."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo is the CPU backend (tests with several ranks on one GPU): reduce a host copy.
+            # Its own handling of device tensors has been seen to hang after a few iterations.
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)    # RCCL: in place, on the device
     return flat
 
 
@@ -67,7 +74,8 @@ def params_in_sync(flat: torch.Tensor, group=None) -> bool:
     """True when every rank holds bit-identical parameters (checked after optimiser steps)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return True
-    lo, hi = flat.clone(), flat.clone()
+    host = flat.is_cuda and dist.get_backend(group) == "gloo"      # (see allreduce_sum_)
+    lo, hi = (flat.cpu(), flat.cpu()) if host else (flat.clone(), flat.clone())
     dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
     return bool(torch.equal(lo, hi))

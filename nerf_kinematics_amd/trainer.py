@@ -192,7 +192,8 @@ class Trainer:
                                                 ray_batch.data_ptr(), R, self.ropts, self.ws_ptr, self.ws_bytes,
                                                 _ptr(self.d_rgb_f), self.d_rgb_c.data_ptr(), gc.data_ptr(), _ptr(gf), st))
             if self.world > 1:
-                torch.distributed.all_reduce(self.grad, group=self.pg)   # one flat buffer, both networks
+                from . import dist as nkdist
+                nkdist.allreduce_sum_(self.grad, self.pg)       # one flat buffer, both networks
             self.iteration += 1
             self.opt_steps += 1
             _lib.check(L.nk_adam_step(self.params.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
