@@ -192,7 +192,7 @@ def test_one_call_and_staged_steps_agree(nk, dev, teacher):
     la = float(a.step(rb, tgt))
     ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
     lb = float(b.step(rb, tgt, events=ev))
-    assert abs(la - lb) < 1e-6 * abs(la)
+    assert abs(la - lb) < 1e-5 * abs(la)
     assert float(a.grad.norm()) > 0
     assert float((a.grad - b.grad).norm() / a.grad.norm()) < 1e-5
     assert float((a.params - b.params).abs().max()) <= 2 * 5e-3 + 1e-6 and float((a.params - b.params).abs().mean()) < 1e-6
