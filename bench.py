@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W          (N == 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (the 400x400 lego configuration the throughput metric is quoted on): synthetic lego -- views of the reference's trained
-lego checkpoint rendered by the HIP path are the "photographs" (the real nerf_synthetic images are
+Workload (the 400x400 lego configuration the throughput metric is quoted on): synthetic lego --
+views of the reference's trained lego checkpoint rendered by the HIP path are the "photographs" (the real nerf_synthetic images are
 not available offline) -- 64 coarse + 128 fine samples, coarse and fine 8x256 skip networks with
 torch.nn.Linear default init, bf16 MFMA compute with fp32 accumulate and fp32 master weights.
 One step = pick random pixels of one view, get_rays, render_rays forward, img2mse on both maps,

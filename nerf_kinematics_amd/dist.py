@@ -1,7 +1,7 @@
 """Data-parallel helpers: rays shard across ranks, the only exchange is ONE all-reduce of the flat
 gradient buffer that holds both networks (RCCL on GPUs via backend "nccl"; gloo in CPU tests).
-The reference is single-GPU (no torch.distributed call site anywhere in /root/reference); this is
-data parallelism over rays is a new capability."""
+The reference is single-GPU (no torch.distributed call site anywhere in /root/reference): data
+parallelism over rays is a new capability."""
 from __future__ import annotations
 
 import os
