@@ -103,8 +103,8 @@ def main():
     tr = Trainer(nk.ARCH_RUN_NERF, nk.ARCH_RUN_NERF, opts, dev, rays_per_step=a.rays)
     sampler = RaySampler(scene, a.rays, seed=1234, rank=rank, world=world)
 
-    mk_ev = lambda: tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
-    ev = [mk_ev() for _ in range(a.steps)]       # (fine start, fine stop, coarse start, coarse stop) per timed step
+    mk_ev = lambda: tuple(torch.cuda.Event(enable_timing=True) for _ in range(6))
+    ev = [mk_ev() for _ in range(a.steps)]       # (fine fwd start/stop, coarse fwd start/stop, fine bwd start/stop) per timed step
     dummy = mk_ev()
 
     def one_step(i, events):
@@ -161,7 +161,11 @@ def main():
                          "kernel_ms": k_ms, "kernel_ms_fine": float(np.mean(t_f)), "kernel_ms_coarse": float(np.mean(t_c)),
                          "bytes_per_launch": bytes_per_launch, "flop_per_launch": flops,
                          "mfma_tflops": flops / (k_ms * 1e-3) / 1e12, "mfma_frac": flops / (k_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                         "step_train_tflops": samples / dt * 3 * FLOP_PER_EVAL_8x256 * 256 / 192 / 1e12},
+                         "step_train_tflops": samples / dt * 3 * FLOP_PER_EVAL_8x256 * 256 / 192 / 1e12,
+                         # the rest of the step, for orientation: the fine network's MLP backward (dZ chain +
+                         # weight-gradient GEMMs) moves 4 928 + 180 B (chain) and 10 688 B (GEMM reads) per point
+                         "backward_fine_ms": float(np.mean([e[4].elapsed_time(e[5]) for e in ev])),
+                         "backward_fine_gbs": a.rays * 192 * (4928 + 180 + 10688) / (float(np.mean([e[4].elapsed_time(e[5]) for e in ev])) * 1e-3) / 1e9},
         }
         if world == 1 and not a.no_cpu_baseline:
             torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))

@@ -139,16 +139,19 @@ class Trainer:
         _lib.check(L.nk_raw2outputs(s["raw_f"].data_ptr(), s["z_all"].data_ptr(), rb, R, Nc + Nf, o,
                                     _lib.STREAM_NOISE_FINE, self.rgb_f.data_ptr(), None, None, None, None, st))
 
-    def _backward_staged(self, ray_batch, R, st):
+    def _backward_staged(self, ray_batch, R, st, events=()):
         L, o, s = self.L, self.ropts, self._stage
+        rec = lambda i: events[i].record() if len(events) > i else None
         Nc, Nf = o.num_coarse, o.num_fine
         rb = ray_batch.data_ptr()
         gc, gf = self.grad_views()
         _lib.check(L.nk_raw2outputs_bwd(s["raw_f"].data_ptr(), s["z_all"].data_ptr(), rb, R, Nc + Nf, o,
                                         _lib.STREAM_NOISE_FINE, self.d_rgb_f.data_ptr(), None, None,
                                         s["d_raw"].data_ptr(), st))
+        rec(4)
         _lib.check(L.nk_mlp_backward(self.fine._c, self.fine.packed.data_ptr(), s["act_f"].data_ptr(),
                                      s["d_raw"].data_ptr(), R, Nc + Nf, s["dz"].data_ptr(), gf.data_ptr(), st))
+        rec(5)
         _lib.check(L.nk_raw2outputs_bwd(s["raw_c"].data_ptr(), s["z_c"].data_ptr(), rb, R, Nc, o,
                                         _lib.STREAM_NOISE_COARSE, self.d_rgb_c.data_ptr(), None, None,
                                         s["d_raw"].data_ptr(), st))
@@ -158,9 +161,10 @@ class Trainer:
     def step(self, ray_batch: torch.Tensor, target: torch.Tensor, events=None) -> torch.Tensor:
         """ray_batch [R,11], target [R,3] on this GPU; returns the loss tensor (device, no sync).
 
-        ``events``: optional four torch.cuda.Event objects recorded around the fine-network (0, 1) and
-        the coarse-network (2, 3) MLP forward launches; the step then issues the same kernels stage
-        by stage."""
+        ``events``: optional torch.cuda.Event objects recorded around the fine-network (0, 1) and the
+        coarse-network (2, 3) MLP forward launches and, when six are given, around the fine network's
+        MLP backward (4, 5: dZ chain + weight-gradient GEMMs); the step then issues the same kernels
+        stage by stage."""
         L, dev = self.L, self.device
         R = ray_batch.shape[0]
         if R != self.R:
@@ -186,7 +190,7 @@ class Trainer:
             self.grad.zero_()
             gc, gf = self.grad_views()
             if staged:
-                self._backward_staged(ray_batch, R, st)
+                self._backward_staged(ray_batch, R, st, events)
             else:
                 _lib.check(L.nk_render_rays_bwd(self.coarse._c, self.coarse.packed.data_ptr(), fc, fp,
                                                 ray_batch.data_ptr(), R, self.ropts, self.ws_ptr, self.ws_bytes,
