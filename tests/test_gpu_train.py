@@ -130,8 +130,9 @@ def test_training_psnr_tracks_the_fp32_oracle(nk, dev):
     sampler's), identical jitter / noise seeds, torch Adam with the same schedule.  The first loss
     agrees to 1e-4; after that the two runs are two trajectories of a chaotic optimisation, so
     held-out PSNR is compared as a mean over nine checkpoints (iterations 300..700): measured
-    differences are -0.02 dB (seed 42) and +0.12 dB (seed 7) with single checkpoints up to 0.26 dB
-    apart in either direction; bounds 0.25 dB on the mean, 0.6 dB on any checkpoint."""
+    differences are -0.02 dB (seed 42) and +0.12 dB (seed 7); over three longer runs (105 checkpoints)
+    +0.03 dB with a standard error of 0.02 dB, single checkpoints up to 0.57 dB apart in either
+    direction; bounds 0.3 dB on the mean, 1 dB on any checkpoint."""
     from nerf_kinematics_amd import datasets
     from nerf_kinematics_amd.metrics import mse2psnr
     from nerf_kinematics_amd.trainer import Trainer, TrainOpts, _init_flat, lr_at
@@ -178,7 +179,7 @@ def test_training_psnr_tracks_the_fp32_oracle(nk, dev):
     print(f"held-out PSNR, mean over {len(d)} checkpoints: HIP {np.mean(hip):.3f} dB, oracle {np.mean(ora):.3f} dB, "
           f"difference {d.mean():+.3f} dB (single checkpoints {d.min():+.3f} .. {d.max():+.3f})")
     assert np.mean(ora) > 17.0
-    assert abs(d.mean()) < 0.25 and np.abs(d).max() < 0.6
+    assert abs(d.mean()) < 0.3 and np.abs(d).max() < 1.0
 
 
 def test_one_call_and_staged_steps_agree(nk, dev, teacher):
