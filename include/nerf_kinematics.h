@@ -171,6 +171,21 @@ int nk_render_rays_bwd(const nk_arch* arch_coarse, const void* packed_coarse,
                        const float* d_rgb_coarse, float* grad_coarse, float* grad_fine,
                        void* stream);
 
+/* ---- render_rays for callers that cannot allocate ------------------------------------------- */
+/* No counterpart in the reference.  For callers that cannot call hipMalloc or pass a workspace:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
+ * result as nk_render_rays_fwd(training = 0): the stage buffers (depths, raw network outputs,
+ * weights; NK_NOALLOC_SCRATCH_BYTES at most) live in a device array that is part of the library
+ * image, one copy per GPU, held until the process ends.  The device the stream belongs to must be
+ * current.  Fails with NK_ERR_WORKSPACE when R rays at opts' sample counts need more than that
+ * (about 5.4 KB per ray at 64 + 128 samples: 12 000 rays); allocates and frees nothing.  All calls
+ * on one GPU share the array: calls that overlap on one GPU (two streams, two threads) race.    */
+#define NK_NOALLOC_SCRATCH_BYTES (64u << 20)
+int nk_render_rays_fwd_noalloc(const nk_arch* arch_coarse, const void* packed_coarse,
+                               const nk_arch* arch_fine, const void* packed_fine,
+                               const float* ray_batch, int64_t R, const nk_render_opts* opts,
+                               const nk_render_out* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

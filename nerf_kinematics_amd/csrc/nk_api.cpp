@@ -3,7 +3,13 @@
 // with the knobs of the nerf.train / nerf.validation blocks of the reference experiment files
 // (/root/reference/trained_models/nerf-pytorch/lego-lowres3/config.yml:46-63).
 #include <string.h>
+#include <mutex>
 #include "nk_common.h"
+
+// Scratch of nk_render_rays_fwd_noalloc: device memory that is part of the loaded code object, one
+// copy per GPU at its own address.  The name is only a host-side handle; host code uses the
+// address hipGetSymbolAddress returns for the current device (static_scratch()).
+static __device__ __align__(256) unsigned char scratch[NK_NOALLOC_SCRATCH_BYTES];
 
 namespace {
 
@@ -51,6 +57,30 @@ int layout(const nk_arch* ac, const nk_arch* af, const nk_render_opts* o, int64_
     }
     L->total = off;
     return NK_OK;
+}
+
+enum { NK_MAX_DEVICES = 64 };
+std::mutex g_scratch_lock;
+void* g_scratch_ptr[NK_MAX_DEVICES];       // per device, filled on the first call with that device current
+
+// Address of `scratch` on the current device (looked up once per device), or nullptr with the
+// error string set.
+void* static_scratch() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { nk_set_error("hipGetDevice failed: %s", hipGetErrorString(e)); return nullptr; }
+    if (dev < 0 || dev >= NK_MAX_DEVICES) { nk_set_error("device %d outside 0..%d", dev, NK_MAX_DEVICES - 1); return nullptr; }
+    std::lock_guard<std::mutex> guard(g_scratch_lock);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            nk_set_error("hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    return g_scratch_ptr[dev];
 }
 
 }  // namespace
@@ -130,4 +160,21 @@ extern "C" int nk_render_rays_bwd(const nk_arch* ac, const void* pc, const nk_ar
         if ((rc = nk_mlp_backward_gemms(both, 2, st)) < 0) return rc;
     }
     return NK_OK;
+}
+
+extern "C" int nk_render_rays_fwd_noalloc(const nk_arch* ac, const void* pc, const nk_arch* af, const void* pf,
+                                          const float* ray_batch, int64_t R, const nk_render_opts* o,
+                                          const nk_render_out* out, void* stream) {
+    WsLayout L;
+    int rc = layout(ac, af, o, R, 0, &L);
+    if (rc < 0) return rc;
+    if (L.total > (int64_t)NK_NOALLOC_SCRATCH_BYTES)
+        NK_FAIL(NK_ERR_WORKSPACE, "nk_render_rays_fwd_noalloc: %lld rays x (%d + %d) samples need %lld bytes of scratch, "
+                "the built-in buffer holds %lld; render in smaller pieces or use nk_render_rays_fwd",
+                (long long)R, o->num_coarse, o->num_fine, (long long)L.total, (long long)NK_NOALLOC_SCRATCH_BYTES);
+    void* ws = static_scratch();
+    if (!ws) return NK_ERR_HIP;
+    // Every region of the inference layout is written in full by the stage that produces it before
+    // a later stage reads it, so nothing of the previous call's contents has to be cleared.
+    return nk_render_rays_fwd(ac, pc, af, pf, ray_batch, R, o, 0, ws, L.total, out, stream);
 }
