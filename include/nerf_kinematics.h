@@ -171,6 +171,25 @@ int nk_render_rays_bwd(const nk_arch* arch_coarse, const void* packed_coarse,
                        const float* d_rgb_coarse, float* grad_coarse, float* grad_fine,
                        void* stream);
 
+/* ---- profiling hook ----------------------------------------------------------------------- */
+/* No counterpart in the reference.  events: `count` hipEvent_t handles created by the caller
+ * (host array, copied; entries may be NULL).  Until it is called again with count 0, every
+ * nk_render_rays_fwd / _bwd call of THIS thread records events[i] on its stream at stage
+ * boundary i, so a caller can time the MLP launches of the shipped path without re-issuing the
+ * stages one by one.  With shared weight-gradient launches (small batches) the fine network's
+ * GEMMs run after the coarse chain: NK_EV_BWD_FINE_GEMMS_END then coincides with
+ * NK_EV_BWD_FINE_CHAIN_END.                                                                  */
+enum {
+    NK_EV_FWD_COARSE_BEGIN = 0, NK_EV_FWD_COARSE_END = 1,     /* coarse Embedder + MLP forward   */
+    NK_EV_FWD_FINE_BEGIN = 2, NK_EV_FWD_FINE_END = 3,         /* fine Embedder + MLP forward     */
+    NK_EV_BWD_FINE_CHAIN_BEGIN = 4, NK_EV_BWD_FINE_CHAIN_END = 5,
+    NK_EV_BWD_FINE_GEMMS_END = 6,
+    NK_EV_BWD_COARSE_CHAIN_BEGIN = 7, NK_EV_BWD_COARSE_CHAIN_END = 8,
+    NK_EV_BWD_END = 9,
+    NK_STAGE_EVENT_COUNT = 10
+};
+int nk_set_stage_events(void** events, int count);
+
 /* ---- render_rays for callers that cannot allocate ------------------------------------------- */
 /* No counterpart in the reference.  For callers that cannot call hipMalloc or pass a workspace:
  * code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same

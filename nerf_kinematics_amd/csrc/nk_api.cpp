@@ -59,6 +59,17 @@ int layout(const nk_arch* ac, const nk_arch* af, const nk_render_opts* o, int64_
     return NK_OK;
 }
 
+// Profiling hook: events of the calling thread, recorded at the stage boundaries of the next
+// nk_render_rays_fwd / _bwd calls (see nk_set_stage_events in the header).
+thread_local hipEvent_t g_stage_events[NK_STAGE_EVENT_COUNT];
+thread_local int g_stage_event_count = 0;
+
+int mark(int idx, void* stream) {
+    if (idx >= g_stage_event_count || !g_stage_events[idx]) return NK_OK;
+    NK_CHECK_HIP(hipEventRecord(g_stage_events[idx], nk_stream(stream)));
+    return NK_OK;
+}
+
 enum { NK_MAX_DEVICES = 64 };
 std::mutex g_scratch_lock;
 void* g_scratch_ptr[NK_MAX_DEVICES];       // per device, filled on the first call with that device current
@@ -85,6 +96,14 @@ void* static_scratch() {
 
 }  // namespace
 
+extern "C" int nk_set_stage_events(void** events, int count) {
+    if (count < 0 || count > NK_STAGE_EVENT_COUNT || (count > 0 && !events))
+        NK_FAIL(NK_ERR_ARG, "nk_set_stage_events: count %d outside 0..%d, or null array", count, (int)NK_STAGE_EVENT_COUNT);
+    for (int i = 0; i < count; ++i) g_stage_events[i] = (hipEvent_t)events[i];
+    g_stage_event_count = count;
+    return NK_OK;
+}
+
 extern "C" int64_t nk_render_workspace_bytes(const nk_arch* coarse, const nk_arch* fine, const nk_render_opts* opts,
                                              int64_t R, int training) {
     WsLayout L;
@@ -110,13 +129,17 @@ extern "C" int nk_render_rays_fwd(const nk_arch* ac, const void* pc, const nk_ar
     float* rgb_c = out->rgb_coarse ? out->rgb_coarse : (float*)(ws + L.rgb_c_tmp);
 
     if ((rc = nk_stratified_z(ray_batch, R, o, z_c, stream)) < 0) return rc;
+    if ((rc = mark(NK_EV_FWD_COARSE_BEGIN, stream)) < 0) return rc;
     if ((rc = nk_mlp_forward(ac, pc, ray_batch, z_c, R, Nc, raw_c, training ? ws + L.act_c : nullptr, stream)) < 0) return rc;
+    if ((rc = mark(NK_EV_FWD_COARSE_END, stream)) < 0) return rc;
     if ((rc = nk_raw2outputs(raw_c, z_c, ray_batch, R, Nc, o, NK_STREAM_NOISE_COARSE, rgb_c, out->disp_coarse,
                              out->acc_coarse, out->depth_coarse, w_c, stream)) < 0) return rc;
     if (Nf > 0) {
         float* z_all = (float*)(ws + L.z_all); float* raw_f = (float*)(ws + L.raw_f);
         if ((rc = nk_sample_pdf(z_c, w_c, R, o, z_all, nullptr, stream)) < 0) return rc;
+        if ((rc = mark(NK_EV_FWD_FINE_BEGIN, stream)) < 0) return rc;
         if ((rc = nk_mlp_forward(af, pf, ray_batch, z_all, R, N, raw_f, training ? ws + L.act_f : nullptr, stream)) < 0) return rc;
+        if ((rc = mark(NK_EV_FWD_FINE_END, stream)) < 0) return rc;
         if ((rc = nk_raw2outputs(raw_f, z_all, ray_batch, R, N, o, NK_STREAM_NOISE_FINE, out->rgb_fine, out->disp_fine,
                                  out->acc_fine, out->depth_fine, nullptr, stream)) < 0) return rc;
     }
@@ -146,20 +169,25 @@ extern "C" int nk_render_rays_bwd(const nk_arch* ac, const void* pc, const nk_ar
     if (fine) {
         if ((rc = nk_raw2outputs_bwd((float*)(ws + L.raw_f), (float*)(ws + L.z_all), ray_batch, R, N, o,
                                      NK_STREAM_NOISE_FINE, d_rgb_fine, nullptr, nullptr, d_raw, stream)) < 0) return rc;
+        if ((rc = mark(NK_EV_BWD_FINE_CHAIN_BEGIN, stream)) < 0) return rc;
         if ((rc = nk_mlp_backward_chain(jf, st)) < 0) return rc;
+        if ((rc = mark(NK_EV_BWD_FINE_CHAIN_END, stream)) < 0) return rc;
         if (!together && (rc = nk_mlp_backward_gemms(&jf, 1, st)) < 0) return rc;
+        if ((rc = mark(NK_EV_BWD_FINE_GEMMS_END, stream)) < 0) return rc;
     }
     if (coarse) {
         if ((rc = nk_raw2outputs_bwd((float*)(ws + L.raw_c), (float*)(ws + L.z_c), ray_batch, R, Nc, o,
                                      NK_STREAM_NOISE_COARSE, d_rgb_coarse, nullptr, nullptr, d_raw, stream)) < 0) return rc;
+        if ((rc = mark(NK_EV_BWD_COARSE_CHAIN_BEGIN, stream)) < 0) return rc;
         if ((rc = nk_mlp_backward_chain(jc, st)) < 0) return rc;
+        if ((rc = mark(NK_EV_BWD_COARSE_CHAIN_END, stream)) < 0) return rc;
         if (!together && (rc = nk_mlp_backward_gemms(&jc, 1, st)) < 0) return rc;
     }
     if (together) {
         const NkBwdJob both[2] = {jf, jc};
         if ((rc = nk_mlp_backward_gemms(both, 2, st)) < 0) return rc;
     }
-    return NK_OK;
+    return mark(NK_EV_BWD_END, stream);
 }
 
 extern "C" int nk_render_rays_fwd_noalloc(const nk_arch* ac, const void* pc, const nk_arch* af, const void* pf,

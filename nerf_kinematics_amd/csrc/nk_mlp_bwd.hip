@@ -45,6 +45,7 @@ struct GemmArgs {
     const char* B[2]; int NB0;
     int64_t n_stages;               // G (a stage = 1 group = 32 points)
     int64_t stages_per_wg;
+    int wg_begin;                   // first workgroup of this product in the launch's 1-D grid
     float* grad;                    // flat gradient
     GemmDst dst[2][2];              // [A segment][B segment]
     int b_off[2];                   // bias gradient origin per A segment (rows as dst[seg][0]), or -1
@@ -91,16 +92,47 @@ NK_D void gemm_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// Up to NK_GEMM_BATCH products of one shape per launch (blockIdx.y picks the product): a
-// workgroup of the next product starts on a CU as soon as that CU's workgroup of the previous one
-// has retired, so the load ramp-up and the atomic epilogue of one product overlap the main loop
-// of another instead of idling the memory system between launches.
+// Up to NK_GEMM_BATCH products of one shape per launch.  The launch is ONE round of workgroups
+// over the chip: the points of all its products are cut into equal K-slices, one per workgroup
+// (product k owns workgroups [wg_begin_k, wg_begin_{k+1})), so every CU streams the same number of
+// bytes.  A workgroup does not add its K-slice into the gradient (device-scope fp32 atomics on
+// one 256-KiB matrix run at ~0.6 TB/s chip-wide): it stores its accumulator tiles to its own
+// slice of a scratch region with plain coalesced stores, and k_dw_reduce sums the slices of each
+// product in a fixed order and adds the result to the gradient, which also makes the gradient
+// bit-reproducible from run to run.
+//   slice layout (floats): [MT*NT tiles][16 accumulator registers][64 lanes], then the bias
+//   partial sums [MT][WN][32].
 enum { NK_GEMM_BATCH = 8 };
-struct GemmBatch { GemmArgs g[NK_GEMM_BATCH]; };
+struct GemmBatch { GemmArgs g[NK_GEMM_BATCH]; int count; float* partial; };
+
+NK_HD int64_t gemm_slice_floats(int MT, int NT, int WN) { return (int64_t)MT * NT * 1024 + (int64_t)MT * WN * 32; }
+
+// Flat gradient index that element (row m of A tile mt, column n-in-tile r of B tile nt) of a
+// product accumulates into, or -1 (padding rows / columns, disabled segment pairs).
+NK_D int64_t gemm_dst_index(const GemmArgs& a, int mt, int nt, int m_in_tile, int r) {
+    const int sa = mt >= a.MA0, sb = nt >= a.NB0;
+    const GemmDst& d = a.dst[sa][sb];
+    if (!d.enabled) return -1;
+    const int n = 32 * (nt - (sb ? a.NB0 : 0)) + r;         // column inside the B segment
+    int dcol;
+    if (d.colmode == NK_COL_IDENT) dcol = n < d.col_count ? d.col_base + n : -1;
+    else {
+        const int s = n >> 4, hh = (n >> 3) & 1, jj = n & 7;
+        const int cc = d.colmode == NK_COL_PEX ? (s < 4 ? nk_pe_xyz_col(8 * s + jj, hh, d.nfreq) : -1)
+                                               : (s < 2 ? nk_pe_dir_col(8 * s + jj, hh, d.nfreq) : -1);
+        dcol = cc >= 0 ? d.col_base + cc : -1;
+    }
+    if (dcol < 0) return -1;
+    const int mr = 32 * (mt - (sa ? a.MA0 : 0)) + m_in_tile - d.row_first;
+    if (mr < 0 || mr >= d.row_count) return -1;
+    return d.w_off + (int64_t)(d.row_dst0 + mr) * d.ld + dcol;
+}
 
 template <int MT, int NT, int WM, int WN>
 __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
-    const GemmArgs& a = batch.g[blockIdx.y];
+    int prod = 0;
+    while (prod + 1 < batch.count && (int)blockIdx.x >= batch.g[prod + 1].wg_begin) ++prod;
+    const GemmArgs& a = batch.g[prod];
     constexpr int TM = MT / WM, TN = NT / WN;       // wave tile, in 32x32 tiles
     static_assert(TM * WM == MT && TN * WN == NT && WM * WN <= 8, "wave grid must tile the output");
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -111,7 +143,7 @@ __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
     constexpr int min_pieces = blocks_per_stage / 8;    // every wave issues at least this many loads per stage
     const bool active = wave < WM * WN;
     const int wm = active ? wave / WN : 0, wn = active ? wave % WN : 0;
-    const int64_t s0 = (int64_t)blockIdx.x * a.stages_per_wg;
+    const int64_t s0 = (int64_t)((int)blockIdx.x - a.wg_begin) * a.stages_per_wg;
     int64_t s1 = s0 + a.stages_per_wg;
     if (s1 > a.n_stages) s1 = a.n_stages;
     if (s0 >= s1) return;
@@ -197,49 +229,74 @@ __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
         }
     }
     if (!active) return;
-    // epilogue: atomically add this K-slice's tiles into the flat gradient
-    const int r = lane & 31, h = lane >> 5;
+    // epilogue: this K-slice's tiles to the workgroup's scratch slice (256 B per store instruction)
+    float* slice = batch.partial + (int64_t)blockIdx.x * gemm_slice_floats(MT, NT, WN);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nt = wn * TN + j;
-        const int sb = nt >= a.NB0;
-        const int n = 32 * (nt - (sb ? a.NB0 : 0)) + r;         // column inside the B segment
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mt = wm * TM + i;
-            const int sa = mt >= a.MA0;
-            const GemmDst& d = a.dst[sa][sb];
-            if (!d.enabled) continue;
-            int dcol = -1;
-            if (d.colmode == NK_COL_IDENT) dcol = n < d.col_count ? d.col_base + n : -1;
-            else {
-                const int s = n >> 4, hh = (n >> 3) & 1, jj = n & 7;
-                const int cc = d.colmode == NK_COL_PEX ? (s < 4 ? nk_pe_xyz_col(8 * s + jj, hh, d.nfreq) : -1)
-                                                       : (s < 2 ? nk_pe_dir_col(8 * s + jj, hh, d.nfreq) : -1);
-                dcol = cc >= 0 ? d.col_base + cc : -1;
-            }
-            if (dcol < 0) continue;
+        for (int j = 0; j < TN; ++j) {
+            float* t = slice + ((wm * TM + i) * NT + (wn * TN + j)) * 1024 + lane;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = 32 * (mt - (sa ? a.MA0 : 0)) + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int mr = m - d.row_first;
-                if (mr >= 0 && mr < d.row_count)
-                    atomicAdd(a.grad + d.w_off + (int64_t)(d.row_dst0 + mr) * d.ld + dcol, acc[i][j][e]);
-            }
+            for (int e = 0; e < 16; ++e) t[e * 64] = acc[i][j][e];
         }
-    }
     if (want_bias) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mt = wm * TM + i;
-            const int sa = mt >= a.MA0;
-            const GemmDst& d = a.dst[sa][0];
             const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-            const int m = 32 * (mt - (sa ? a.MA0 : 0)) + r, mr = m - d.row_first;
-            if (a.b_off[sa] >= 0 && h == 0 && mr >= 0 && mr < d.row_count)
-                atomicAdd(a.grad + a.b_off[sa] + d.row_dst0 + mr, tot);
+            if (lane < 32) slice[MT * NT * 1024 + ((wm * TM + i) * WN + wn) * 32 + lane] = tot;
         }
     }
+}
+
+// Second stage: sums every output element of a product over the product's slices and adds it to
+// the flat gradient.  A workgroup owns 64 consecutive elements (one accumulator register of one
+// tile); its four wavefronts take the slices w = 0, 1, 2, 3 (mod 4) with eight loads in flight
+// each and meet in LDS, so the order of the additions is fixed.  blockIdx.y = product; the last
+// workgroups of a product do the bias rows.
+__global__ __launch_bounds__(256) void k_dw_reduce(GemmBatch batch, int MT, int NT, int WN) {
+    __shared__ float part[4][64];
+    const GemmArgs& a = batch.g[blockIdx.y];
+    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int n_rows = MT * NT * 16;                     // 64-element rows of the weight part
+    const int64_t stride = gemm_slice_floats(MT, NT, WN);
+    const int n_slices = (int)((a.n_stages + a.stages_per_wg - 1) / a.stages_per_wg);
+    const float* p0 = batch.partial + (int64_t)a.wg_begin * stride;
+    int64_t dst = -1;
+    const float* p = nullptr;
+    int terms = 1;                                       // values per slice that fold into the element
+    if ((int)blockIdx.x < n_rows) {
+        const int tile = blockIdx.x >> 4, e = blockIdx.x & 15;
+        dst = gemm_dst_index(a, tile / NT, tile % NT, (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), lane & 31);
+        p = p0 + (int64_t)blockIdx.x * 64 + lane;
+    } else {
+        const int b = ((int)blockIdx.x - n_rows) * 64 + lane;       // bias element: tile row mt, row r
+        if (b < MT * 32) {
+            const int mt = b >> 5, r = b & 31;
+            const int sa = mt >= a.MA0;
+            const GemmDst& d = a.dst[sa][0];
+            const int mr = 32 * (mt - (sa ? a.MA0 : 0)) + r - d.row_first;
+            if (a.b_off[sa] >= 0 && mr >= 0 && mr < d.row_count) dst = a.b_off[sa] + d.row_dst0 + mr;
+            p = p0 + (int64_t)n_rows * 64 + mt * WN * 32 + r;
+            terms = WN;
+        }
+    }
+    float sum = 0.0f;
+    if (dst >= 0) {
+        for (int k = 0; k < terms; ++k) {
+            const float* q = p + k * 32;
+            float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int w = sg;
+            for (; w + 28 < n_slices; w += 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] += q[(int64_t)(w + 4 * u) * stride];
+            }
+            for (; w < n_slices; w += 4) s[0] += q[(int64_t)w * stride];
+            sum += ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        }
+    }
+    part[sg][lane] = sum;
+    __syncthreads();
+    if (sg == 0 && dst >= 0) a.grad[dst] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 static GemmDst gemm_dst(int w_off, int ld, int row_first, int row_count, int colmode, int col_base, int col_count,
@@ -269,23 +326,40 @@ static void queue_gemm(GemmQueue& q, const char* A0, int wA0, const char* A1, in
         for (int j = 0; j < 2; ++j) g.dst[i][j] = dst[i][j];
     g.b_off[0] = b_off0; g.b_off[1] = b_off1;
     g.n_stages = G;
-    // Split-K width: one workgroup per CU for large batches; fewer when a workgroup would see too
-    // few stages, because every workgroup pays the same atomic epilogue (one output matrix): at
-    // least 3 stages per output tile, between 8 and 48.
-    static const int env_wgs = []() { const char* e = getenv("NK_GEMM_WGS"); return e ? atoi(e) : 0; }();
-    static const int env_k = []() { const char* e = getenv("NK_GEMM_STAGES_PER_TILE"); return e ? atoi(e) : 3; }();
-    int min_stages = env_k * q.MT[q.n] * q.NT[q.n];
-    min_stages = min_stages < 8 ? 8 : (min_stages > 48 ? 48 : min_stages);
-    int64_t target_wgs = env_wgs > 0 ? env_wgs : g.n_stages / min_stages;
-    if (env_wgs <= 0) target_wgs = target_wgs < 64 ? 64 : (target_wgs > 256 ? 256 : target_wgs);
-    g.stages_per_wg = (g.n_stages + target_wgs - 1) / target_wgs;
-    if (g.stages_per_wg < 1) g.stages_per_wg = 1;
+    g.stages_per_wg = 0; g.wg_begin = 0;      // set per launch (flush_gemms)
     g.grad = grad;
     ++q.n;
 }
 
-static int flush_gemms(GemmQueue& q, hipStream_t stream) {
+// Workgroups per launch: one per CU of the current device (NK_GEMM_WGS overrides).
+enum { NK_GEMM_MIN_STAGES = 6, NK_MAX_GPUS = 64 };
+static int gemm_wg_limit() {
+    static const int env_wgs = []() { const char* e = getenv("NK_GEMM_WGS"); return e ? atoi(e) : 0; }();
+    if (env_wgs > 0) return env_wgs;
+    static int cus[NK_MAX_GPUS];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NK_MAX_GPUS) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+// Scratch for the K-slice partial sums of one launch: one slice per workgroup, sized for the
+// largest product shape of the network width.
+static int64_t gemm_partial_bytes(int W) {
+    // (MT, NT, WN) of the largest slice: skip layer (8,10,2) for width 256, (4,6,2) for width 128
+    const int64_t f = W == 256 ? gemm_slice_floats(8, 10, 2) : gemm_slice_floats(4, 6, 2);
+    const int64_t g = W == 256 ? gemm_slice_floats(9, 8, 8) : gemm_slice_floats(5, 4, 4);
+    return (f > g ? f : g) * 4 * gemm_wg_limit();
+}
+
+static int flush_gemms(GemmQueue& q, float* partial, int64_t partial_bytes, hipStream_t stream) {
     bool done[32] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NK_MAX_GPUS) dev = 0;
     for (int first = 0; first < q.n; ++first) {
         if (done[first]) continue;
         const int MT = q.MT[first], NT = q.NT[first];
@@ -294,32 +368,62 @@ static int flush_gemms(GemmQueue& q, hipStream_t stream) {
         for (int k = first; k < q.n && count < NK_GEMM_BATCH; ++k)
             if (!done[k] && q.MT[k] == MT && q.NT[k] == NT) { batch.g[count++] = q.g[k]; done[k] = true; }
         for (int k = count; k < NK_GEMM_BATCH; ++k) batch.g[k] = batch.g[0];
-        unsigned nwg = 1;        // products of two networks differ in length: the longest sets the grid
+        batch.count = count;
+        // K-slice length: the launch's stages spread over one workgroup per CU (at least a few
+        // stages each, so the load pipeline fills), every product rounded up to whole slices
+        const int limit = gemm_wg_limit();
+        int64_t total = 0;
+        for (int k = 0; k < count; ++k) total += batch.g[k].n_stages;
+        int64_t spw = (total + limit - 1) / limit;
+        if (spw < NK_GEMM_MIN_STAGES) spw = NK_GEMM_MIN_STAGES;
+        unsigned nwg = 0;
+        for (;; ++spw) {
+            nwg = 0;
+            for (int k = 0; k < count; ++k) nwg += (unsigned)((batch.g[k].n_stages + spw - 1) / spw);
+            if ((int)nwg <= limit || count >= limit) break;
+        }
+        nwg = 0;
         for (int k = 0; k < count; ++k) {
-            const GemmArgs& g = batch.g[k];
-            const unsigned n = (unsigned)((g.n_stages + g.stages_per_wg - 1) / g.stages_per_wg);
-            if (n > nwg) nwg = n;
+            batch.g[k].stages_per_wg = spw;
+            batch.g[k].wg_begin = (int)nwg;
+            nwg += (unsigned)((batch.g[k].n_stages + spw - 1) / spw);
         }
         const int lds_bytes = NK_GEMM_RING * (MT + NT) * 2048;
-        const dim3 grid(nwg, count), block(512);
+        const dim3 grid(nwg), block(512);
+        batch.partial = partial;
+        int WN = 0;
         // (A tiles, B tiles) -> wave grid; every shape the supported networks produce
 #define NK_GEMM_CASE(MT_, NT_, WM_, WN_) \
         if (MT == MT_ && NT == NT_) { \
-            NK_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_gemm<MT_, NT_, WM_, WN_>, \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+            static bool lds_allowed[NK_MAX_GPUS]; \
+            if (!lds_allowed[dev]) { \
+                NK_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_gemm<MT_, NT_, WM_, WN_>, \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+                lds_allowed[dev] = true; \
+            } \
+            WN = WN_; \
+            if ((int64_t)nwg * gemm_slice_floats(MT_, NT_, WN_) * 4 > partial_bytes) \
+                NK_FAIL(NK_ERR_WORKSPACE, "dW GEMM: partial-sum scratch too small for %u slices of %d x %d tiles", nwg, MT, NT); \
             hipLaunchKernelGGL((k_dw_gemm<MT_, NT_, WM_, WN_>), grid, block, lds_bytes, stream, batch); \
         } else
-        // width 256: trunk / feature, trunk 0, rgb, alpha, skip (h + gamma(x)), views (feat + gamma(d))
-        NK_GEMM_CASE(8, 8, 2, 4) NK_GEMM_CASE(8, 2, 4, 2) NK_GEMM_CASE(1, 4, 1, 4) NK_GEMM_CASE(1, 8, 1, 8)
+        // width 256: trunk, trunk 0, rgb, feature + alpha, skip (h + gamma(x)), views (feat + gamma(d))
+        NK_GEMM_CASE(8, 8, 2, 4) NK_GEMM_CASE(8, 2, 4, 2) NK_GEMM_CASE(1, 4, 1, 4) NK_GEMM_CASE(9, 8, 1, 8)
         NK_GEMM_CASE(8, 10, 4, 2) NK_GEMM_CASE(4, 9, 2, 3)
-        // width 128: the same six ((1, 4) doubles as its alpha shape)
-        NK_GEMM_CASE(4, 4, 2, 4) NK_GEMM_CASE(4, 2, 4, 2) NK_GEMM_CASE(1, 2, 1, 2)
+        // width 128: the same six
+        NK_GEMM_CASE(4, 4, 2, 4) NK_GEMM_CASE(4, 2, 4, 2) NK_GEMM_CASE(1, 2, 1, 2) NK_GEMM_CASE(5, 4, 1, 4)
         NK_GEMM_CASE(4, 6, 2, 2) NK_GEMM_CASE(2, 5, 2, 1)
         NK_FAIL(NK_ERR_UNSUPPORTED, "dW GEMM: no kernel for %d x %d tiles", MT, NT);
 #undef NK_GEMM_CASE
         NK_CHECK_LAUNCH("k_dw_gemm");
+        const dim3 rgrid((unsigned)(MT * NT * 16 + (MT * 32 + 63) / 64), (unsigned)count);
+        hipLaunchKernelGGL(k_dw_reduce, rgrid, dim3(256), 0, stream, batch, MT, NT, WN);
+        NK_CHECK_LAUNCH("k_dw_reduce");
     }
     return NK_OK;
+}
+
+static int64_t dz_region_bytes(const NkPlan& p, int64_t R, int32_t n) {
+    return (nk_dz_offset(p, nk_dz_count(p), nk_groups(R * (int64_t)n)) + 255) & ~(int64_t)255;
 }
 
 extern "C" int64_t nk_dz_bytes(const nk_arch* arch, int64_t R, int32_t n) {
@@ -327,7 +431,8 @@ extern "C" int64_t nk_dz_bytes(const nk_arch* arch, int64_t R, int32_t n) {
     int rc = nk_build_plan(arch, &p);
     if (rc < 0) return rc;
     if (R <= 0 || n <= 0) { nk_set_error("nk_dz_bytes: non-positive size"); return NK_ERR_ARG; }
-    return nk_dz_offset(p, nk_dz_count(p), nk_groups(R * (int64_t)n));
+    // dZ regions, then the partial-sum scratch of the weight-gradient launches
+    return dz_region_bytes(p, R, n) + gemm_partial_bytes(p.W);
 }
 
 // dZ chain of one network: d_raw -> dZ of every layer (bf16, into job.dz)
@@ -383,15 +488,11 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
         d[0][1] = gemm_dst(lviews.w_off, lviews.in_dim, 0, WD, NK_COL_PED, W, 32, p.Ld);
         queue_gemm(q, dz(1), WD, nullptr, 0, act(2 + D), W, act(1), 32, G, grad, d, lviews.b_off, -1);
     }
-    {   // alpha: row 3 of dOut against h_{D-1}
-        GemmDst d[2][2] = {};
-        d[0][0] = gemm_dst(lalpha.w_off, lalpha.in_dim, 3, 1, NK_COL_IDENT, 0, W, 0);
-        queue_gemm(q, dz(0), 32, nullptr, 0, act(2 + D - 1), W, nullptr, 0, G, grad, d, lalpha.b_off, -1);
-    }
-    {   // feature layer: dZ_feat against h_{D-1}
+    {   // feature layer and alpha: dZ_feat and row 3 of dOut, side by side, against h_{D-1} (read once)
         GemmDst d[2][2] = {};
         d[0][0] = gemm_dst(lfeat.w_off, lfeat.in_dim, 0, W, NK_COL_IDENT, 0, W, 0);
-        queue_gemm(q, dz(2), W, nullptr, 0, act(2 + D - 1), W, nullptr, 0, G, grad, d, lfeat.b_off, -1);
+        d[1][0] = gemm_dst(lalpha.w_off, lalpha.in_dim, 3, 1, NK_COL_IDENT, 0, W, 0);
+        queue_gemm(q, dz(2), W, dz(0), 32, act(2 + D - 1), W, nullptr, 0, G, grad, d, lfeat.b_off, lalpha.b_off);
     }
     for (int L = D - 1; L >= 0; --L) {     // trunk
         const NkLayer& l = p.layer[L];
@@ -421,7 +522,21 @@ int nk_mlp_backward_gemms(const NkBwdJob* jobs, int count, hipStream_t st) {
         int rc = queue_network_gemms(q, jobs[k]);
         if (rc < 0) return rc;
     }
-    return flush_gemms(q, st);
+    // the partial-sum scratch sits behind the first network's dZ regions (see nk_dz_bytes)
+    NkPlan p0;
+    int rc = nk_build_plan(jobs[0].arch, &p0);
+    if (rc < 0) return rc;
+    float* partial = (float*)((char*)jobs[0].dz + dz_region_bytes(p0, jobs[0].R, jobs[0].n));
+    int64_t partial_bytes = gemm_partial_bytes(p0.W);
+    if (count > 1) {        // products of both networks share launches: slices sized for the wider one
+        NkPlan p1;
+        if ((rc = nk_build_plan(jobs[1].arch, &p1)) < 0) return rc;
+        if (p1.W > p0.W) {
+            partial = (float*)((char*)jobs[1].dz + dz_region_bytes(p1, jobs[1].R, jobs[1].n));
+            partial_bytes = gemm_partial_bytes(p1.W);
+        }
+    }
+    return flush_gemms(q, partial, partial_bytes, st);
 }
 
 extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const void* act_save, const float* d_raw,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "nk_render_workspace_bytes": (_I64, [_PA, _PA, _PO, _I64, C.c_int]),
     "nk_render_rays_fwd": (C.c_int, [_PA, _P, _PA, _P, _P, _I64, _PO, C.c_int, _P, _I64, _PR, _P]),
     "nk_render_rays_bwd": (C.c_int, [_PA, _P, _PA, _P, _P, _I64, _PO, _P, _I64, _P, _P, _P, _P, _P]),
+    "nk_set_stage_events": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "nk_render_rays_fwd_noalloc": (C.c_int, [_PA, _P, _PA, _P, _P, _I64, _PO, _PR, _P]),
 }
 
