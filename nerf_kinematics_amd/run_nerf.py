@@ -102,6 +102,11 @@ def render_path(tr: Trainer, scene: Scene, cfg: dict, poses_json: str, outdir: s
 
 def main(argv=None) -> int:
     a = parse_args(argv)
+    # NK_STALL_DUMP_SECONDS=n: if the process is still running after n seconds, every thread's
+    # Python stack goes to stderr and the process exits (multi-rank runs: shows where each rank waits)
+    if os.environ.get("NK_STALL_DUMP_SECONDS"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["NK_STALL_DUMP_SECONDS"]), exit=True)
     over = {}
     if a.logdir:
         over.setdefault("experiment", {})["logdir"] = a.logdir

@@ -79,7 +79,11 @@ class Trainer:
         self.params[:nc] = _init_flat(arch_coarse, seed).to(self.device)
         if use_fine:
             self.params[nc_pad:] = _init_flat(arch_fine, seed + 1).to(self.device)
-        self.grad = torch.zeros_like(self.params)
+        # gradient and (behind it, 256-byte aligned) the loss scalar share one buffer: one fill per step
+        n_pad = (nc_pad + nf + 63) // 64 * 64
+        self._grad_loss = torch.zeros(n_pad + 64, dtype=torch.float32, device=self.device)
+        self.grad = self._grad_loss[:nc_pad + nf]
+        self.loss = self._grad_loss[n_pad:n_pad + 1]
         self.exp_avg = torch.zeros_like(self.params)
         self.exp_avg_sq = torch.zeros_like(self.params)
         self.coarse = NeRFModel(arch_coarse, self.params[:nc])
@@ -100,7 +104,6 @@ class Trainer:
         mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
         self.rgb_c, self.rgb_f = mk(R, 3), (mk(R, 3) if self.fine is not None else None)
         self.d_rgb_c, self.d_rgb_f = mk(R, 3), (mk(R, 3) if self.fine is not None else None)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.out = _lib.NkRenderOut(_ptr(self.rgb_f), None, None, None, _ptr(self.rgb_c), None, None, None)
 
     def grad_views(self):
@@ -109,62 +112,12 @@ class Trainer:
         return gc, gf
 
     # -- one optimisation step -----------------------------------------------------------------
-    def _forward_staged(self, ray_batch, R, st, events):
-        """The kernel sequence of nk_render_rays_fwd issued stage by stage, so that HIP events can
-        bracket the fine-network MLP launch on the stream it runs on (used by bench.py)."""
-        L, o = self.L, self.ropts
-        Nc, Nf = o.num_coarse, o.num_fine
-        if not hasattr(self, "_stage"):
-            mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
-            acts = lambda m, n: torch.empty(_lib.check(L.nk_act_bytes(m._c, R, n)), dtype=torch.uint8, device=self.device)
-            self._stage = dict(z_c=mk(R, Nc), raw_c=mk(R, Nc, 4), w_c=mk(R, Nc), act_c=acts(self.coarse, Nc),
-                               z_all=mk(R, Nc + Nf), raw_f=mk(R, Nc + Nf, 4), act_f=acts(self.fine, Nc + Nf),
-                               d_raw=mk(R, Nc + Nf, 4),
-                               dz=torch.empty(_lib.check(L.nk_dz_bytes(self.fine._c, R, Nc + Nf)), dtype=torch.uint8,
-                                              device=self.device))
-        s = self._stage
-        rb = ray_batch.data_ptr()
-        _lib.check(L.nk_stratified_z(rb, R, o, s["z_c"].data_ptr(), st))
-        events[2].record()
-        _lib.check(L.nk_mlp_forward(self.coarse._c, self.coarse.packed.data_ptr(), rb, s["z_c"].data_ptr(), R, Nc,
-                                    s["raw_c"].data_ptr(), s["act_c"].data_ptr(), st))
-        events[3].record()
-        _lib.check(L.nk_raw2outputs(s["raw_c"].data_ptr(), s["z_c"].data_ptr(), rb, R, Nc, o, _lib.STREAM_NOISE_COARSE,
-                                    self.rgb_c.data_ptr(), None, None, None, s["w_c"].data_ptr(), st))
-        _lib.check(L.nk_sample_pdf(s["z_c"].data_ptr(), s["w_c"].data_ptr(), R, o, s["z_all"].data_ptr(), None, st))
-        events[0].record()
-        _lib.check(L.nk_mlp_forward(self.fine._c, self.fine.packed.data_ptr(), rb, s["z_all"].data_ptr(), R, Nc + Nf,
-                                    s["raw_f"].data_ptr(), s["act_f"].data_ptr(), st))
-        events[1].record()
-        _lib.check(L.nk_raw2outputs(s["raw_f"].data_ptr(), s["z_all"].data_ptr(), rb, R, Nc + Nf, o,
-                                    _lib.STREAM_NOISE_FINE, self.rgb_f.data_ptr(), None, None, None, None, st))
-
-    def _backward_staged(self, ray_batch, R, st, events=()):
-        L, o, s = self.L, self.ropts, self._stage
-        rec = lambda i: events[i].record() if len(events) > i else None
-        Nc, Nf = o.num_coarse, o.num_fine
-        rb = ray_batch.data_ptr()
-        gc, gf = self.grad_views()
-        _lib.check(L.nk_raw2outputs_bwd(s["raw_f"].data_ptr(), s["z_all"].data_ptr(), rb, R, Nc + Nf, o,
-                                        _lib.STREAM_NOISE_FINE, self.d_rgb_f.data_ptr(), None, None,
-                                        s["d_raw"].data_ptr(), st))
-        rec(4)
-        _lib.check(L.nk_mlp_backward(self.fine._c, self.fine.packed.data_ptr(), s["act_f"].data_ptr(),
-                                     s["d_raw"].data_ptr(), R, Nc + Nf, s["dz"].data_ptr(), gf.data_ptr(), st))
-        rec(5)
-        _lib.check(L.nk_raw2outputs_bwd(s["raw_c"].data_ptr(), s["z_c"].data_ptr(), rb, R, Nc, o,
-                                        _lib.STREAM_NOISE_COARSE, self.d_rgb_c.data_ptr(), None, None,
-                                        s["d_raw"].data_ptr(), st))
-        _lib.check(L.nk_mlp_backward(self.coarse._c, self.coarse.packed.data_ptr(), s["act_c"].data_ptr(),
-                                     s["d_raw"].data_ptr(), R, Nc, s["dz"].data_ptr(), gc.data_ptr(), st))
-
-    def step(self, ray_batch: torch.Tensor, target: torch.Tensor, events=None) -> torch.Tensor:
+    def step(self, ray_batch: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """ray_batch [R,11], target [R,3] on this GPU; returns the loss tensor (device, no sync).
 
-        ``events``: optional torch.cuda.Event objects recorded around the fine-network (0, 1) and the
-        coarse-network (2, 3) MLP forward launches and, when six are given, around the fine network's
-        MLP backward (4, 5: dZ chain + weight-gradient GEMMs); the step then issues the same kernels
-        stage by stage."""
+        The whole step is nk_render_rays_fwd, nk_mse_loss, nk_render_rays_bwd, (all-reduce),
+        nk_adam_step and the re-pack of the bf16 weight images, all on the current stream.  To time
+        its stages, hand HIP events to ``nk_set_stage_events`` before calling."""
         L, dev = self.L, self.device
         R = ray_batch.shape[0]
         if R != self.R:
@@ -173,28 +126,20 @@ class Trainer:
         self.ropts.seed = (self.opts.seed + 0x9E3779B1 * (self.iteration + 1) + 7919 * self._rank()) & 0xFFFFFFFF
         fc = self.fine._c if self.fine is not None else None
         fp = self.fine.packed.data_ptr() if self.fine is not None else None
-        staged = events is not None and self.fine is not None
-        if not staged and self.ws is None:
+        if self.ws is None:
             self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
             self.ws_ptr = (self.ws.data_ptr() + 255) & ~255
         with torch.cuda.device(dev):
-            if staged:
-                self._forward_staged(ray_batch, R, st, events)
-            else:
-                _lib.check(L.nk_render_rays_fwd(self.coarse._c, self.coarse.packed.data_ptr(), fc, fp,
-                                                ray_batch.data_ptr(), R, self.ropts, 1, self.ws_ptr, self.ws_bytes,
-                                                self.out, st))
-            self.loss.zero_()
+            _lib.check(L.nk_render_rays_fwd(self.coarse._c, self.coarse.packed.data_ptr(), fc, fp,
+                                            ray_batch.data_ptr(), R, self.ropts, 1, self.ws_ptr, self.ws_bytes,
+                                            self.out, st))
+            self._grad_loss.zero_()                             # gradient and loss in one fill
             _lib.check(L.nk_mse_loss(self.rgb_c.data_ptr(), _ptr(self.rgb_f), target.data_ptr(), R, 1.0,
                                      self.loss.data_ptr(), self.d_rgb_c.data_ptr(), _ptr(self.d_rgb_f), st))
-            self.grad.zero_()
             gc, gf = self.grad_views()
-            if staged:
-                self._backward_staged(ray_batch, R, st, events)
-            else:
-                _lib.check(L.nk_render_rays_bwd(self.coarse._c, self.coarse.packed.data_ptr(), fc, fp,
-                                                ray_batch.data_ptr(), R, self.ropts, self.ws_ptr, self.ws_bytes,
-                                                _ptr(self.d_rgb_f), self.d_rgb_c.data_ptr(), gc.data_ptr(), _ptr(gf), st))
+            _lib.check(L.nk_render_rays_bwd(self.coarse._c, self.coarse.packed.data_ptr(), fc, fp,
+                                            ray_batch.data_ptr(), R, self.ropts, self.ws_ptr, self.ws_bytes,
+                                            _ptr(self.d_rgb_f), self.d_rgb_c.data_ptr(), gc.data_ptr(), _ptr(gf), st))
             if self.world > 1:
                 from . import dist as nkdist
                 nkdist.allreduce_sum_(self.grad, self.pg)       # one flat buffer, both networks

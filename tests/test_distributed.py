@@ -6,6 +6,7 @@ render uses."""
 import math
 import os
 import socket
+import sys
 
 import torch
 import torch.distributed as dist
@@ -88,3 +89,25 @@ def test_two_rank_gradient_equals_single_process():
     assert ok
     assert float(g1.norm()) > 0
     assert float((g1 - g2).norm() / g1.norm()) < 1e-5
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the script starts two ranks itself (gloo here,
+    no GPU work with --launch-check) and rank 0 prints ONE JSON line that says n_gpus == 2."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["NK_DIST_BACKEND"] = "gloo"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["launch_check"] is True
+    # under a launcher (WORLD_SIZE set) the script is one rank and starts nothing
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env1,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1

@@ -45,6 +45,8 @@ def _batch(dev):
 
 
 def _worker(rank, world, port, q):
+    import faulthandler
+    faulthandler.dump_traceback_later(120, exit=True)      # a stalled rank shows where it waits
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")
     from nerf_kinematics_amd import dist as nd
@@ -60,6 +62,16 @@ def _worker(rank, world, port, q):
     loss = float(tr.step(rb[sl].contiguous(), target[sl].contiguous()))
     in_sync = nd.params_in_sync(tr.params)
     q.put((rank, loss, tr.grad.cpu().numpy().copy(), tr.params.cpu().numpy().copy(), in_sync, img))
+    # twelve more data-parallel steps with a sharded render in between: the ranks stay in lockstep
+    later = True
+    for i in range(12):
+        sl = nd.shard_rows(R, (rank + i) % world, world)
+        tr.step(rb[sl].contiguous(), target[sl].contiguous())
+        if i % 4 == 3:
+            tr.render(rb[:64], chunk=64, shard=True)
+        later = later and nd.params_in_sync(tr.params)
+    q.put((rank, "later", later))
+    faulthandler.cancel_dump_traceback_later()
     torch.distributed.barrier()
     nd.shutdown()
 
@@ -73,12 +85,17 @@ def test_two_rank_trainer_step_equals_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = {}
-    for _ in range(2):
-        rank, loss, grad, params, ok, img = q.get(timeout=300)
+    got, later = {}, {}
+    for _ in range(4):
+        item = q.get(timeout=150)
+        if item[1] == "later":
+            later[item[0]] = item[2]
+            continue
+        rank, loss, grad, params, ok, img = item
         got[rank] = (loss, torch.from_numpy(grad), torch.from_numpy(params), ok, torch.from_numpy(img))
+    assert later == {0: True, 1: True}          # parameters bit-identical on both ranks after every later step
     for p in procs:
-        p.join(timeout=300)
+        p.join(timeout=150)
         assert p.exitcode == 0
     dev = torch.device("cuda:0")
     one = _make_trainer(R, dev)
@@ -100,3 +117,30 @@ def test_two_rank_trainer_step_equals_single_process():
     # ... and the same Adam step (first step moves every parameter by ~lr; near-zero gradients may flip)
     d = (got[0][2] - p1).abs()
     assert float(d.mean()) < 1e-5 and float(d.max()) <= 2 * 5e-3 + 1e-6
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: two ranks (gloo, both on this GPU) run the real
+    training step; the one JSON line reports both ranks' rays."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NK_DIST_BACKEND="gloo", NK_STALL_DUMP_SECONDS="140")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rays", "1024",
+           "--views", "2", "--res", "64"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=160)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["rays_per_step_per_gpu"] == 1024
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 1024 * 192 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
+    assert rec["roofline"]["bound"] == "mfma" and 0 < rec["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in rec and "heldout_psnr" not in rec          # single-GPU legs only
+    # strong scaling: the global batch is split
+    out = subprocess.run(cmd + ["--scaling", "strong"], env=env, capture_output=True, text=True, timeout=160)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["scaling"] == "strong" and rec["config"]["rays_per_step_per_gpu"] == 512
