@@ -85,7 +85,7 @@ def validate(cfg: dict) -> dict:
             raise ConfigError(f"nerf.{block}.num_fine must be >= 0")
     if cfg["optimizer"].get("type", "Adam") != "Adam":
         raise ConfigError(f"optimizer.type: only Adam is supported, got {cfg['optimizer']['type']!r}")
-    if cfg["dataset"]["type"] not in ("blender", "robot", "transforms", "teacher"):
+    if cfg["dataset"]["type"] not in ("blender", "robot", "transforms", "teacher", "forward_grid"):
         raise ConfigError(f"dataset.type: unknown dataset type {cfg['dataset']['type']!r}")
     return cfg
 

@@ -10,8 +10,15 @@ Dataset kinds follow ``dataset.type`` of the reference's experiment files:
                 ``llffhold``, forward-facing NDC with near 0 / far 1): ``transforms.json`` as
                 written by the pose converter (``fl_x fl_y cx cy w h``,
                 /root/reference/parser_instant_ngp.py:128-145), every ``llffhold``-th frame held
-                out.  The reference's loader for this type is not vendored, so the split rule and
-                the area down-sampling here follow the LLFF convention the key names come from.
+                out (the LLFF rule the key name comes from; the reference's loader for this type
+                is not vendored).  Images are down-sampled by plain striding, ``img[::f, ::f]``:
+                the reference's own 160 x 90 validation target
+                (/root/reference/results/wheel/nerf-pytorch/imgs/reals/TestNERF_0_original.png)
+                equals ``TestNERF 0.jpg[::8, ::8]`` to 44.5 dB (JPEG decoder differences), against
+                20 dB for any filtered resize.
+``forward_grid`` synthetic forward-facing capture (the 1280 x 720 NDC configuration; the fox
+                photographs ship without poses): cameras on a square grid in the z = 0 plane
+                looking down -z at the lego teacher placed at z = -4, NDC rays, near 0 / far 1.
 ``transforms``  any single transforms.json of either flavour.
 ``teacher``     synthetic: views of a trained checkpoint rendered by the HIP path itself (the
                 nerf_synthetic photographs are not redistributable with the repository).
@@ -112,10 +119,14 @@ class Scene:
 # ---------------------------------------------------------------------------------------------
 # file loaders (host side: PIL + json)
 # ---------------------------------------------------------------------------------------------
-def _read_image(path: str, size: Optional[Tuple[int, int]] = None) -> np.ndarray:
+def _read_image(path: str, size: Optional[Tuple[int, int]] = None, stride: int = 0) -> np.ndarray:
+    """8-bit image, optionally reduced: ``stride`` f > 1 keeps every f-th row and column (the
+    reference's robot loader), otherwise ``size`` (W, H) by area averaging."""
     from PIL import Image
     with Image.open(path) as im:
         im = im.convert("RGBA" if im.mode in ("RGBA", "LA", "P") else "RGB")
+        if stride > 1:
+            return np.ascontiguousarray(np.asarray(im, dtype=np.uint8)[::stride, ::stride])
         if size is not None and im.size != size:
             im = im.resize(size, Image.BOX)          # area averaging (exact for integer factors)
         return np.asarray(im, dtype=np.uint8)
@@ -191,7 +202,7 @@ def read_transforms(path: str) -> Dict:
 
 def load_transforms(path: str, downsample: int = 1, near: float = 2.0, far: float = 6.0, ndc: bool = False,
                     holdout: int = 0, white_background: bool = False, device="cuda",
-                    val_path: Optional[str] = None, load_images: bool = True) -> Scene:
+                    val_path: Optional[str] = None, load_images: bool = True, strided: bool = False) -> Scene:
     """One transforms.json (+ optionally a ``_val`` file) -> Scene.
 
     ``holdout`` > 0 holds out frames 0, holdout, 2*holdout, ... as the test/validation split (the
@@ -211,8 +222,12 @@ def load_transforms(path: str, downsample: int = 1, near: float = 2.0, far: floa
         from PIL import Image
         with Image.open(paths[0]) as im:
             W0, H0 = im.size
-    W, H = W0 // downsample, H0 // downsample
-    sx, sy = W / W0, H / H0
+    if strided:                 # rows / columns 0, f, 2f, ...: ceil(n / f) of them
+        W, H = -(-W0 // downsample), -(-H0 // downsample)
+        sx = sy = 1.0 / downsample
+    else:
+        W, H = W0 // downsample, H0 // downsample
+        sx, sy = W / W0, H / H0
     if meta["fl_x"]:
         fx = float(meta["fl_x"]) * sx
         fy = float(meta["fl_y"] or meta["fl_x"]) * sy
@@ -220,7 +235,7 @@ def load_transforms(path: str, downsample: int = 1, near: float = 2.0, far: floa
         fx = fy = 0.5 * W / math.tan(0.5 * float(meta["camera_angle_x"]))
     cx = float(meta["cx"]) * sx if meta["cx"] is not None else W * 0.5
     cy = float(meta["cy"]) * sy if meta["cy"] is not None else H * 0.5
-    images = _stack([_read_image(p, (W, H)) for p in paths], device) if load_images else None
+    images = _stack([_read_image(p, (W, H), downsample if strided else 0) for p in paths], device) if load_images else None
     poses = np.stack([np.array(f["transform_matrix"], dtype=np.float32) for f in frames])
     n = len(frames)
     if holdout > 0:
@@ -246,7 +261,11 @@ def load_scene(cfg: dict, device="cuda") -> Scene:
         hold = int(d.get("llffhold", 0)) if kind == "robot" else 0
         return load_transforms(path, int(d.get("downsample_factor", 1)), float(d["near"]), float(d["far"]),
                                not bool(d.get("no_ndc", True)), hold, white, device,
-                               val_path=path.replace(".json", "_val.json"))
+                               val_path=path.replace(".json", "_val.json"), strided=(kind == "robot"))
+    if kind == "forward_grid":
+        return forward_grid_scene(d.get("teacher_weights"), int(d.get("grid", 5)), int(d.get("width", 1280)),
+                                  int(d.get("height", 720)), device, holdout=int(d.get("llffhold", 8)),
+                                  spacing=float(d.get("spacing", 0.25)))
     if kind == "teacher":
         return teacher_scene(d.get("teacher_weights"), int(d.get("train_views", 100)), int(d.get("val_views", 25)),
                              int(d.get("resolution", 400)), device, near=float(d["near"]), far=float(d["far"]))
@@ -290,6 +309,53 @@ def teacher_scene(weights_npz: Optional[str], n_train: int, n_val: int, res: int
             for s in range(0, rb.shape[0], 65536):
                 rgb = render_rays(rb[s:s + 65536], c, f, num_coarse=num_coarse, num_fine=num_fine)[0]
                 imgs[k].view(-1, 3)[s:s + 65536] = (rgb.clamp(0, 1) * 255.0 + 0.5).to(torch.uint8)
+    scene.images = imgs
+    return scene
+
+
+def forward_grid_scene(weights_npz: Optional[str], grid: int, width: int, height: int, device, holdout: int = 8,
+                       spacing: float = 0.25, depth: float = 4.0, num_coarse: int = 64, num_fine: int = 128) -> Scene:
+    """Forward-facing synthetic capture: ``grid`` x ``grid`` cameras in the z = 0 plane, ``spacing``
+    apart, all looking down -z (identity rotation), horizontal field of view of the lego scenes.
+    The photographs are the trained lego checkpoint rendered by the HIP path with the object
+    ``depth`` in front of the camera plane (ordinary rays, near 2 / far 6 around the object); the
+    scene itself is the NDC configuration: near 0, far 1, NDC near plane 1, every ``holdout``-th
+    view held out."""
+    from .model import ARCH_LEGO_CKPT, NeRFModel
+    from .render import render_rays
+    if weights_npz is None:
+        weights_npz = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                   "lego_lowres3_weights.npz")
+    w = np.load(weights_npz)
+    dev = torch.device(device)
+    c = NeRFModel(ARCH_LEGO_CKPT, torch.from_numpy(w["coarse"]).to(dev))
+    f = NeRFModel(ARCH_LEGO_CKPT, torch.from_numpy(w["fine"]).to(dev))
+    focal = 0.5 * width / math.tan(0.5 * LEGO_CAMERA_ANGLE_X)
+    poses = []
+    for gy in range(grid):
+        for gx in range(grid):
+            m = np.eye(4, dtype=np.float32)
+            m[0, 3] = (gx - 0.5 * (grid - 1)) * spacing
+            m[1, 3] = (gy - 0.5 * (grid - 1)) * spacing
+            poses.append(m)
+    n = len(poses)
+    i_test = np.arange(n)[::holdout] if holdout > 0 else np.zeros(0, np.int64)
+    i_train = np.setdiff1d(np.arange(n), i_test)
+    scene = Scene(None, np.stack(poses), height, width, focal, focal, width * 0.5, height * 0.5, 0.0, 1.0, True, False,
+                  i_train, i_test, i_test)
+    # the teacher sees the same cameras from its own frame: object at the origin, cameras at z = +depth,
+    # lying on its side (the lego scenes are z-up; the cameras here look along -z)
+    to_teacher = np.array([[1, 0, 0, 0], [0, 0, -1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=np.float32)
+    lift = np.eye(4, dtype=np.float32); lift[2, 3] = depth
+    photo = Scene(None, np.stack([to_teacher @ lift @ p for p in poses]), height, width, focal, focal, width * 0.5,
+                  height * 0.5, depth - 2.0, depth + 2.0, False, False)
+    imgs = torch.empty(n, height, width, 3, dtype=torch.uint8, device=dev)
+    with torch.no_grad():
+        for k in range(n):
+            rb = photo.rays(k, dev)
+            for s in range(0, rb.shape[0], 131072):
+                rgb = render_rays(rb[s:s + 131072], c, f, num_coarse=num_coarse, num_fine=num_fine)[0]
+                imgs[k].view(-1, 3)[s:s + 131072] = (rgb.clamp(0, 1) * 255.0 + 0.5).to(torch.uint8)
     scene.images = imgs
     return scene
 

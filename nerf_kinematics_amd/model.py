@@ -81,9 +81,20 @@ class Arch:
         lx = int(model_cfg.get("num_encoding_fn_xyz", 10))
         ld = int(model_cfg.get("num_encoding_fn_dir", 4))
         if typ == "FlexibleNeRFModel":
+            # The reference's training script builds this class with its default depth whatever the
+            # file says: both vendored checkpoints hold layer1 + three layers_xyz under
+            # ``num_layers: 8, skip_connect_every: 3``.  ``honour_num_layers: true`` opts into the
+            # depth the file names (no skip connection in this lineage's kernels).
             depth = 4
             if state_dict is not None:
                 depth = 1 + sum(1 for k in state_dict if k.startswith("layers_xyz.") and k.endswith(".weight"))
+            elif model_cfg.get("honour_num_layers"):
+                depth = int(model_cfg.get("num_layers", 4))
+            elif int(model_cfg.get("num_layers", 4)) != 4:
+                import warnings
+                warnings.warn(f"FlexibleNeRFModel: num_layers: {model_cfg.get('num_layers')} / skip_connect_every are not "
+                              "honoured (the reference trains 4 trunk layers whatever they say); building 4 layers. "
+                              "Set honour_num_layers: true in the model block to build the depth named.", stacklevel=2)
             return Arch(depth=depth, width=W, skip=-1, dir_width=W // 2, n_freq_xyz=lx, n_freq_dir=ld,
                         relu_first=False, relu_feat=True, lineage="flexible")
         if typ in ("NeRF", "run_nerf"):

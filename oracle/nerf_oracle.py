@@ -103,31 +103,43 @@ def rand_normal(seed: int, stream: int, idx: np.ndarray) -> np.ndarray:
 # --------------------------------------------------------------------------------------------
 # rays
 # --------------------------------------------------------------------------------------------
-def get_rays(H: int, W: int, focal: float, c2w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def _fxfy(focal):
+    return (focal, focal) if not isinstance(focal, (tuple, list)) else (focal[0], focal[1])
+
+
+def get_rays(H: int, W: int, focal, c2w: torch.Tensor, cx: Optional[float] = None,
+             cy: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Pinhole rays, Blender/OpenGL camera convention (x right, y up, camera looks down -z).
 
     dir = ((i - W/2)/f, -(j - H/2)/f, -1), rays_d = R @ dir (not normalised), rays_o = t.
-    Returns ``rays_o, rays_d`` of shape [H, W, 3]; pixel (row j, column i).
+    Returns ``rays_o, rays_d`` of shape [H, W, 3]; pixel (row j, column i).  ``focal`` may be a
+    pair (fx, fy) and the principal point may be given, for cameras described by
+    ``fl_x fl_y cx cy`` (/root/reference/parser_instant_ngp.py:128-145).
     """
     c2w = torch.as_tensor(c2w)
     dt = c2w.dtype
+    fx, fy = _fxfy(focal)
+    cx = W * 0.5 if cx is None else cx
+    cy = H * 0.5 if cy is None else cy
     j, i = torch.meshgrid(torch.arange(H, dtype=dt), torch.arange(W, dtype=dt), indexing="ij")
-    dirs = torch.stack([(i - W * 0.5) / focal, -(j - H * 0.5) / focal, -torch.ones_like(i)], -1)
+    dirs = torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)], -1)
     rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
     rays_o = c2w[:3, 3].expand(rays_d.shape)
     return rays_o, rays_d
 
 
-def ndc_rays(H: int, W: int, focal: float, near: float, rays_o: torch.Tensor,
+def ndc_rays(H: int, W: int, focal, near: float, rays_o: torch.Tensor,
              rays_d: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Forward-facing NDC warp (NeRF paper appendix C).  Parity unpinned (no reference fixture)."""
+    """Forward-facing NDC warp (NeRF paper appendix C).  Parity unpinned (no reference fixture).
+    ``focal`` may be a pair (fx, fy): the x row of the projection uses fx, the y row fy."""
+    fx, fy = _fxfy(focal)
     t = -(near + rays_o[..., 2]) / rays_d[..., 2]
     rays_o = rays_o + t[..., None] * rays_d
-    o0 = -1.0 / (W / (2.0 * focal)) * rays_o[..., 0] / rays_o[..., 2]
-    o1 = -1.0 / (H / (2.0 * focal)) * rays_o[..., 1] / rays_o[..., 2]
+    o0 = -1.0 / (W / (2.0 * fx)) * rays_o[..., 0] / rays_o[..., 2]
+    o1 = -1.0 / (H / (2.0 * fy)) * rays_o[..., 1] / rays_o[..., 2]
     o2 = 1.0 + 2.0 * near / rays_o[..., 2]
-    d0 = -1.0 / (W / (2.0 * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
-    d1 = -1.0 / (H / (2.0 * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d0 = -1.0 / (W / (2.0 * fx)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = -1.0 / (H / (2.0 * fy)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
     d2 = -2.0 * near / rays_o[..., 2]
     return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
 

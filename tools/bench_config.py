@@ -17,6 +17,8 @@ ap.add_argument("config")
 ap.add_argument("--rays", type=int, default=None)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--as-trained", action="store_true", help="4 trunk layers as in the reference's checkpoints (default: as the YAML says)")
+ap.add_argument("--scene", action="store_true", help="train on the dataset the YAML names (default: a small lego-teacher scene)")
+ap.add_argument("--downsample", type=int, default=None, help="override dataset.downsample_factor")
 a = ap.parse_args()
 cfg = C.load_config(a.config)
 opts = TrainOpts.from_config(cfg)
@@ -28,7 +30,14 @@ arch = Arch.from_config(mc)
 if not a.as_trained and mc["type"] == "FlexibleNeRFModel":
     arch = Arch(int(mc["num_layers"]), arch.width, -1, arch.dir_width, arch.n_freq_xyz, arch.n_freq_dir, False, True, "flexible")
 tr = Trainer(arch, arch, opts, dev)
-scene = teacher_scene(None, 8, 0, 200, dev)
+if a.scene:
+    from nerf_kinematics_amd.datasets import load_scene
+    if a.downsample is not None:
+        cfg["dataset"]["downsample_factor"] = a.downsample
+    scene = load_scene(cfg, dev)
+    print(f"scene: {len(scene.i_train)} training views {scene.W}x{scene.H}, ndc={scene.ndc}")
+else:
+    scene = teacher_scene(None, 8, 0, 200, dev)
 smp = RaySampler(scene, opts.num_random_rays, opts.seed)
 for i in range(20):
     tr.step(*smp.next(i))
