@@ -173,3 +173,54 @@ def test_other_workgroup_sizes_in_a_child_process(nk):
     assert " passed" in r.stdout and "mlp_forward" not in r.stderr
     n = int(r.stdout.strip().splitlines()[-1].split(" passed")[0].split()[-1])
     assert n >= 9, r.stdout[-500:]        # 3 + 2 backward cases, 4 forward cases
+
+
+def test_gradient_distance_to_the_fp32_oracle(nk, dev):
+    """What bf16 MFMA operands cost the gradient, as numbers: the headline shape (8x256 coarse +
+    fine, 64 + 128 samples, jitter and noise on) after 300 training iterations on the lego-teacher
+    scene, HIP gradient of the NeRF loss on one batch against the gradient of the FP32 oracle (no
+    bf16 emulation anywhere) at the same parameters, rays, colours and seed.  Reported per
+    parameter tensor (relative L2 distance, cosine); bounded for the whole gradient of each
+    network and for every tensor that carries more than 1 % of its network's gradient norm."""
+    from nerf_kinematics_amd.datasets import RaySampler, teacher_scene
+    from nerf_kinematics_amd.trainer import Trainer, TrainOpts
+    arch = nk.ARCH_RUN_NERF
+    scene = teacher_scene(None, 8, 0, 100, dev)
+    opts = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=1024, perturb=True, radiance_field_noise_std=0.2,
+                     lr=5e-4, seed=42)
+    tr = Trainer(arch, arch, opts, dev)
+    smp = RaySampler(scene, 1024, seed=3)
+    for i in range(300):
+        tr.step(*smp.next(i))
+    rb, target = smp.next(300)
+    rb, target = rb[:192].clone(), target[:192].clone()
+    fc, ff = tr.coarse.flat.detach().clone(), tr.fine.flat.detach().clone()
+    kw = dict(perturb=True, radiance_field_noise_std=0.2, seed=77)
+    c, f = nk.NeRFModel(arch, fc.clone()), nk.NeRFModel(arch, ff.clone())
+    c.flat.requires_grad_(True); f.flat.requires_grad_(True)
+    out = nk.render_rays(rb, c, f, num_coarse=64, num_fine=128, **kw)
+    loss = ((out[3] - target) ** 2).mean() + ((out[0] - target) ** 2).mean()
+    loss.backward()
+    fco, ffo = fc.cpu().clone().requires_grad_(True), ff.cpu().clone().requires_grad_(True)
+    co, fo = O.NeRFNet.from_flat(oarch(arch), fco), O.NeRFNet.from_flat(oarch(arch), ffo)
+    lref = O.nerf_loss(O.render_rays(rb.cpu(), co, fo, O.RenderOpts(64, 128, **kw)), target.cpu())
+    lref.backward()
+    print(f"loss: HIP {float(loss):.6f}, fp32 oracle {float(lref):.6f}")
+    assert abs(float(loss) - float(lref)) < 2e-2 * float(lref)
+    for name, got, ref in (("coarse", c.flat.grad.cpu(), fco.grad), ("fine", f.flat.grad.cpu(), ffo.grad)):
+        tot = float(ref.norm())
+        rel = float((got - ref).norm()) / tot
+        cos = float(torch.dot(got, ref) / (got.norm() * ref.norm()))
+        print(f"{name}: whole gradient rel L2 {rel:.4f}, cosine {cos:.5f}, |g| {tot:.4e}")
+        assert rel < 0.12 and cos > 0.994
+        off = 0
+        for pname, (o_, i_) in arch.param_shapes():
+            for kind, cnt in (("weight", o_ * i_), ("bias", o_)):
+                g, r = got[off:off + cnt], ref[off:off + cnt]
+                off += cnt
+                share = float(r.norm()) / tot
+                tr_rel = float((g - r).norm() / r.norm().clamp_min(1e-30))
+                tr_cos = float(torch.dot(g, r) / (g.norm() * r.norm()).clamp_min(1e-30))
+                print(f"    {pname}.{kind:6s} share {share:6.3f}  rel L2 {tr_rel:.4f}  cosine {tr_cos:.5f}")
+                if share > 0.01:
+                    assert tr_rel < 0.16 and tr_cos > 0.99, (name, pname, kind, tr_rel, tr_cos)
