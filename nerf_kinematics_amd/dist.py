@@ -70,6 +70,24 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+def allreduce_sum_start(flat: torch.Tensor, group=None):
+    """Start summing `flat` over ranks in place and return a handle for allreduce_wait (None when
+    the sum is already complete).  RCCL: the collective runs on its own stream behind everything
+    queued on the current stream so far, so kernels launched afterwards overlap it."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return None
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        allreduce_sum_(flat, group)         # host copy, synchronous (tests with several ranks on one GPU)
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def allreduce_wait(handle) -> None:
+    """Make the current stream wait for a collective started by allreduce_sum_start."""
+    if handle is not None:
+        handle.wait()
+
+
 def params_in_sync(flat: torch.Tensor, group=None) -> bool:
     """True when every rank holds bit-identical parameters (checked after optimiser steps)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

@@ -14,6 +14,10 @@ LIB_PATH = os.path.join(_HERE, "libnerfkin.so")
 NK_LINEAGE_RUN_NERF = 0
 NK_LINEAGE_FLEXIBLE = 1
 
+# nk_render_rays_bwd runs the weight-gradient products of both networks in shared launches up to
+# this many fine-network points per call (NK_PAIR_GEMM_MAX_POINTS in csrc/nk_api.cpp)
+PAIR_GEMM_MAX_POINTS = 1 << 20
+
 STREAM_STRATIFIED, STREAM_PDF, STREAM_NOISE_COARSE, STREAM_NOISE_FINE, STREAM_PIXELS = 0, 1, 2, 3, 4
 
 

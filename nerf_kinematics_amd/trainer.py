@@ -89,6 +89,7 @@ class Trainer:
         self.coarse = NeRFModel(arch_coarse, self.params[:nc])
         self.fine = NeRFModel(arch_fine, self.params[nc_pad:]) if use_fine else None
         self._nc, self._nc_pad = nc, nc_pad
+        self.overlap_allreduce: Optional[bool] = None      # None: decided per batch size (_split_allreduce)
         self.iteration = 0          # training iterations done (drives the learning-rate decay and the RNG)
         self.opt_steps = 0          # optimiser steps done (Adam bias correction; survives resume)
         self._alloc(self.R)
@@ -137,12 +138,23 @@ class Trainer:
             _lib.check(L.nk_mse_loss(self.rgb_c.data_ptr(), _ptr(self.rgb_f), target.data_ptr(), R, 1.0,
                                      self.loss.data_ptr(), self.d_rgb_c.data_ptr(), _ptr(self.d_rgb_f), st))
             gc, gf = self.grad_views()
-            _lib.check(L.nk_render_rays_bwd(self.coarse._c, self.coarse.packed.data_ptr(), fc, fp,
-                                            ray_batch.data_ptr(), R, self.ropts, self.ws_ptr, self.ws_bytes,
-                                            _ptr(self.d_rgb_f), self.d_rgb_c.data_ptr(), gc.data_ptr(), _ptr(gf), st))
-            if self.world > 1:
+            bwd = lambda d_f, d_c: _lib.check(L.nk_render_rays_bwd(
+                self.coarse._c, self.coarse.packed.data_ptr(), fc, fp, ray_batch.data_ptr(), R, self.ropts, self.ws_ptr,
+                self.ws_bytes, d_f, d_c, gc.data_ptr(), _ptr(gf), st))
+            if self._split_allreduce(R):
+                # the fine network's gradient is complete before the coarse backward starts: its half
+                # of the flat buffer is reduced while the coarse chain and products run
                 from . import dist as nkdist
-                nkdist.allreduce_sum_(self.grad, self.pg)       # one flat buffer, both networks
+                bwd(_ptr(self.d_rgb_f), None)
+                h_f = nkdist.allreduce_sum_start(self.grad[self._nc_pad:], self.pg)
+                bwd(None, self.d_rgb_c.data_ptr())
+                h_c = nkdist.allreduce_sum_start(self.grad[:self._nc_pad], self.pg)
+                nkdist.allreduce_wait(h_f); nkdist.allreduce_wait(h_c)
+            else:
+                bwd(_ptr(self.d_rgb_f), self.d_rgb_c.data_ptr())
+                if self.world > 1:
+                    from . import dist as nkdist
+                    nkdist.allreduce_sum_(self.grad, self.pg)       # one flat buffer, both networks
             self.iteration += 1
             self.opt_steps += 1
             _lib.check(L.nk_adam_step(self.params.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
@@ -153,6 +165,19 @@ class Trainer:
             if self.fine is not None:
                 self.fine.pack()
         return self.loss
+
+    def _split_allreduce(self, R: int) -> bool:
+        """Two backward calls with an all-reduce per network (overlapped) instead of one call and one
+        all-reduce.  Default: whenever nk_render_rays_bwd would run the two networks' products in
+        separate launches anyway (batches above 2^20 fine points); small batches keep the shared
+        launches and ONE collective, where latency counts.  ``overlap_allreduce`` overrides."""
+        if self.fine is None:
+            return False
+        if self.overlap_allreduce is not None:
+            return bool(self.overlap_allreduce)
+        if self.world == 1:
+            return False
+        return R * (self.ropts.num_coarse + self.ropts.num_fine) > _lib.PAIR_GEMM_MAX_POINTS
 
     def _rank(self) -> int:
         return torch.distributed.get_rank(self.pg) if self.world > 1 else 0

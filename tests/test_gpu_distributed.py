@@ -65,6 +65,7 @@ def _worker(rank, world, port, q):
     # twelve more data-parallel steps with a sharded render in between: the ranks stay in lockstep
     later = True
     for i in range(12):
+        tr.overlap_allreduce = (i % 2 == 1)       # odd steps: two backward calls, one all-reduce per network
         sl = nd.shard_rows(R, (rank + i) % world, world)
         tr.step(rb[sl].contiguous(), target[sl].contiguous())
         if i % 4 == 3:

@@ -213,6 +213,22 @@ def test_one_call_step_equals_the_stage_by_stage_step(nk, dev, teacher):
     assert float((a.grad - b.grad).norm() / a.grad.norm()) < 1e-5
 
 
+def test_split_backward_equals_single_call(nk, dev, teacher):
+    """The data-parallel step's two backward calls (fine, then coarse: an all-reduce per network can
+    start in between) give the gradient of the single call: bit for bit at a size where the
+    networks' products run in separate launches anyway, to summation order where they are shared."""
+    from nerf_kinematics_amd.datasets import RaySampler
+    for rays, exact in ((16384, True), (512, False)):
+        rb, tgt = RaySampler(teacher, rays, seed=6).next(0)
+        a, b = _trainer(nk, dev, rays=rays, seed=4), _trainer(nk, dev, rays=rays, seed=4)
+        b.overlap_allreduce = True
+        a.step(rb, tgt); b.step(rb, tgt)
+        if exact:
+            assert torch.equal(a.grad, b.grad) and torch.equal(a.params, b.params)
+        else:
+            assert float((a.grad - b.grad).norm() / a.grad.norm()) < 1e-5
+
+
 def test_gradient_is_bit_reproducible(nk, dev, teacher):
     """Weight gradients are summed in a fixed order (K-slices through scratch, then one reduce
     kernel): the same step twice gives the same bits, at a shared-launch and at a per-network size."""
