@@ -72,7 +72,33 @@ struct WStream {
     int cur;                // ring slot holding the stage being consumed
     int nxt;                // ring slot the next issue fills
     int wave, lane;
+    bool spread_ok = false; // NK_DMA_SPREAD: set by the kernel once the ring is primed
+    // NK_DMA_SPREAD (forward chain): the pieces of a stage's stream load are issued one every third
+    // k-step from inside the tile's MFMA loop instead of as a burst after the barrier, where all
+    // waves of the CU queue for the address path at once (-3 % inference, -1 % with saves).
+#ifndef NK_DMA_SPREAD
+#define NK_DMA_SPREAD 1
+#endif
+    int pend_nb;            // NK_DMA_SPREAD: blocks of the load announced by issue_next, issued piece by piece
+    // piece i of the announced load: block wave + i * NW (issued from inside the tile's MFMA loop)
+    NK_D void piece(int i) {
+        const int b = wave + i * NW;
+        if (b < pend_nb) {
+            char* dst = ring + nxt * slot_bytes;
+            const uint32_t voff = lane * 16;
+            const uint32_t l = (uint32_t)(uintptr_t)(NK_LDS char*)(dst + b * 1024);
+            const char* sb = g + (int64_t)b * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(l), "v"(voff), "s"(sb) : "memory");
+        }
+    }
+    NK_D void finish() {    // after the last piece
+        g += (int64_t)pend_nb * 1024;
+        nxt = nxt == 2 ? 0 : nxt + 1;
+        pend_nb = 0;
+    }
     NK_D void issue_next(int nb) {       // nb = 1-KiB blocks of the stage after next (0: none left)
+        if (NK_DMA_SPREAD && spread_ok) { pend_nb = nb; return; }
         char* dst = ring + nxt * slot_bytes;
 #ifndef NK_DMA_ASM
 #define NK_DMA_ASM 1
@@ -139,8 +165,8 @@ NK_D f32x16 lds_bias(const char* stage, int nk, int h) {
 // One 32-row output tile: NK0 k-steps against fragments b0[], then NK1 against b1[].  The A
 // fragments come from LDS with an explicit 8-deep read-ahead so the MFMA chain never waits on a
 // just-issued ds_read.
-template <int NK0, int NK1, int NPRE = 0>   // NPRE: other LDS reads issued just before (the bias fragment)
-NK_D f32x16 tile_run(f32x16 acc, const char* stage, int lane, const Frag* b0, const Frag* b1) {
+template <int NK0, int NK1, int NPRE = 0, typename WS = void>   // NPRE: other LDS reads issued just before (the bias fragment)
+NK_D f32x16 tile_run(f32x16 acc, const char* stage, int lane, const Frag* b0, const Frag* b1, WS* ws = nullptr) {
     constexpr int NK = NK0 + NK1;
 #ifndef NK_LOOKAHEAD
 #define NK_LOOKAHEAD 8
@@ -158,9 +184,19 @@ NK_D f32x16 tile_run(f32x16 acc, const char* stage, int lane, const Frag* b0, co
         const bf16x8 b = ks < NK0 ? b0[ks < NK0 ? ks : 0].b : b1[ks >= NK0 ? ks - NK0 : 0].b;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % LA], b, acc, 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (!__is_same(WS, void)) {       // one piece of the announced stream load every third k-step
+            if (NK_DMA_SPREAD && ks % 3 == 1 && ks / 3 < 6) ws->piece(ks / 3);
+        }
         if (ks + LA < NK) {
             a[ks % LA] = *(const bf16x8*)(base + (ks + LA) * 1024);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+    if constexpr (!__is_same(WS, void)) {
+        if (NK_DMA_SPREAD) {
+#pragma unroll
+            for (int i = (NK + 1) / 3; i < 6; ++i) ws->piece(i);    // pieces a short tile had no k-step for
+            ws->finish();
         }
     }
     return acc;

@@ -19,6 +19,7 @@ struct BwdArgs {
     const float* d_raw;     // [P,4]
     char* dz;               // dZ regions
     int64_t P, G;
+    int stagger;            // upper half of each workgroup's waves run the staggered stage order
 };
 
 #include "nk_bwd_chain.inc"
@@ -449,6 +450,8 @@ int nk_mlp_backward_chain(const NkBwdJob& j, hipStream_t st) {
     a.act = (const char*)j.act; a.d_raw = j.d_raw; a.dz = (char*)j.dz;
     a.P = j.R * (int64_t)j.n; a.G = nk_groups(a.P);
     const int nw = nk_waves_per_wg(1);
+    static const int env_stagger = []() { const char* e = getenv("NK_STAGGER_BWD"); return e ? atoi(e) : 1; }();
+    a.stagger = env_stagger;
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
     if (p.W == 256) {
         if (nw == 8) hipLaunchKernelGGL((k_mlp_bwd<256, 128, 8>), grid, block, 3 * (16 + 1) * 1024, st, a);

@@ -127,6 +127,7 @@ struct FwdArgs {
     char* act;             // saved activations or null
     int64_t P, G;
     int n;                 // samples per ray
+    int stagger;           // upper half of each workgroup's waves run the staggered stage order
 #ifdef NK_STAMPS
     long long* stamps;     // debug build: per-wave cycle stamps of one workgroup
 #endif
@@ -158,6 +159,8 @@ extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const flo
     { const char* e = getenv("NK_STAMP_PTR"); a.stamps = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
     const int nw = nk_waves_per_wg(0);
+    static const int env_stagger = []() { const char* e = getenv("NK_STAGGER_FWD"); return e ? atoi(e) : 0; }();
+    a.stagger = env_stagger;
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
     const bool save = act_save != nullptr;
 #define NK_FWD_LAUNCH(W_, WD_, NW_, LDS_) do { \

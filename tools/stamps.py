@@ -1,11 +1,11 @@
 """Per-section time breakdown of the forward chain kernel (dev tool; needs the NK_STAMPS build:
-every source compiled with -DNK_STAMPS into tools/ab/lib_stamps.so)."""
+every source compiled with -DNK_STAMPS into tools/exp/lib_stamps.so)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import numpy as np
 from nerf_kinematics_amd import lib as L_
-L_.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ab", "lib_stamps.so")
+L_.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exp", "lib_stamps.so")
 import nerf_kinematics_amd as nk
 from nerf_kinematics_amd.trainer import _init_flat
 

@@ -1,5 +1,5 @@
 """Per-stage breakdown inside trunk layer 2 of the forward chain kernel (dev tool; needs the
--DNK_STAMPS=2 build in tools/ab/lib_stamps.so).  Stamps per stage: start, after the
+-DNK_STAMPS=2 build in tools/exp/lib_stamps.so).  Stamps per stage: start, after the
 stream-load issue, after the tile stores, after the MFMA chain is issued, after wait + barrier;
 the next stage's start closes the epilogue."""
 import os, sys
@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import numpy as np
 from nerf_kinematics_amd import lib as L_
-L_.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ab", "lib_stamps.so")
+L_.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exp", "lib_stamps.so")
 import nerf_kinematics_amd as nk
 from nerf_kinematics_amd.trainer import _init_flat
 
