@@ -56,6 +56,20 @@ typedef struct nk_arch {
     int32_t lineage;     /* NK_LINEAGE_*                                               */
 } nk_arch;
 
+/* Per-iteration scalars of a training step kept in DEVICE memory, so that a step whose launches
+ * were captured into a HIP graph can be replayed with new values (kernel arguments are frozen at
+ * capture; these are read by the kernels when they run).  The caller writes one of these before
+ * each replay (a 32-byte copy on the same stream).  No counterpart in the reference.           */
+typedef struct nk_step_state {
+    uint32_t render_seed;         /* what nk_render_opts.seed would be this iteration      */
+    uint32_t pixel_seed;          /* seed of nk_sample_training_rays                       */
+    uint64_t pixel_counter;       /* counter of nk_sample_training_rays                    */
+    int32_t  view;                /* index into the camera table / image stack             */
+    float    adam_step_size;      /* (float)(lr / (1 - beta1^step))                        */
+    float    adam_bc2_sqrt;       /* (float)sqrt(1 - beta2^step)                           */
+    int32_t  reserved;
+} nk_step_state;
+
 /* nerf.train / nerf.validation of config.yml:46-63 */
 typedef struct nk_render_opts {
     int32_t num_coarse;
@@ -65,6 +79,9 @@ typedef struct nk_render_opts {
     int32_t white_background;
     float   radiance_field_noise_std;
     uint32_t seed;                /* seed of the counter-based RNG streams                */
+    int32_t  reserved;
+    const nk_step_state* state;   /* device pointer or NULL; when set, the kernels take the seed
+                                     from state->render_seed when they run and `seed` is ignored */
 } nk_render_opts;
 
 /* Camera for nk_get_rays: intrinsics as in transforms.json (fl_x, fl_y, cx, cy) and a 3x4
@@ -111,6 +128,13 @@ int nk_get_rays(const nk_camera* cam /*host*/, const int32_t* pixel_idx, int64_t
 int nk_sample_training_rays(const nk_camera* cam /*host*/, const uint8_t* image, int32_t channels,
                             int32_t white_background, uint32_t seed, uint64_t counter, int64_t R,
                             float* ray_batch, float* target, int32_t* pixel_idx, void* stream);
+/* The same with everything that changes per iteration read on the device: cams = table of
+ * nk_camera in device memory (all H x W equal), images = stack of 8-bit images image_stride bytes
+ * apart; view, seed and counter come from *state when the kernel runs (graph replay).          */
+int nk_sample_training_rays_dev(const nk_camera* cams /*device*/, int32_t n_views, const uint8_t* images,
+                                int64_t image_stride, int32_t channels, int32_t white_background,
+                                const nk_step_state* state /*device*/, int64_t R, float* ray_batch,
+                                float* target, int32_t* pixel_idx, void* stream);
 /* Coarse depths: linspace in depth or disparity + stratified jitter (render_rays, first part) */
 int nk_stratified_z(const float* ray_batch, int64_t R, const nk_render_opts* opts, float* z,
                     void* stream);
@@ -150,6 +174,14 @@ int nk_mse_loss(const float* rgb_coarse, const float* rgb_fine, const float* tar
 int nk_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  int64_t step, double lr, double beta1, double beta2, double eps, float grad_scale,
                  void* stream);
+
+/* *state_dev = *state_host, stream-ordered: the struct travels as a kernel argument (copied at the
+ * call), so the host copy may be overwritten as soon as the call returns.                      */
+int nk_set_step_state(const nk_step_state* state_host, nk_step_state* state_dev, void* stream);
+/* nk_adam_step with the two step-dependent scalars read from *state on the device (graph replay). */
+int nk_adam_step_dev(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                     const nk_step_state* state /*device*/, double beta1, double beta2, double eps,
+                     float grad_scale, void* stream);
 
 /* ---- render_rays -------------------------------------------------------------------------- */
 /* Workspace for R rays; `training` != 0 adds the activation and gradient scratch.           */

@@ -64,6 +64,41 @@ __global__ void k_sample_training_rays(CamArgs a, const uint8_t* __restrict__ im
     if (pixel_idx) pixel_idx[r] = (int32_t)pix;
 }
 
+__global__ void k_sample_training_rays_dev(const nk_camera* __restrict__ cams, const uint8_t* __restrict__ images,
+                                           int64_t image_stride, int channels, int white,
+                                           const nk_step_state* __restrict__ st, int64_t R, float* __restrict__ rb,
+                                           float* __restrict__ target, int32_t* __restrict__ pixel_idx) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int view = st->view;
+    const nk_camera cam = cams[view];
+    const uint64_t npix = (uint64_t)cam.H * (uint64_t)cam.W;
+    const int64_t pix = (int64_t)(((uint64_t)nk_rand_u32(st->pixel_seed, NK_STREAM_PIXELS, st->pixel_counter + (uint64_t)r) * npix) >> 32);
+    ray_row(cam, pix, rb + r * 11);
+    const uint8_t* px = images + (int64_t)view * image_stride + pix * channels;
+    float c[3] = {(float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f};
+    if (channels == 4 && white) {
+        const float al = (float)px[3] / 255.0f;
+        for (int k = 0; k < 3; ++k) c[k] = __fadd_rn(__fmul_rn(c[k], al), 1.0f - al);
+    }
+    target[r * 3 + 0] = c[0]; target[r * 3 + 1] = c[1]; target[r * 3 + 2] = c[2];
+    if (pixel_idx) pixel_idx[r] = (int32_t)pix;
+}
+
+extern "C" int nk_sample_training_rays_dev(const nk_camera* cams, int32_t n_views, const uint8_t* images,
+                                           int64_t image_stride, int32_t channels, int32_t white_background,
+                                           const nk_step_state* state, int64_t R, float* ray_batch, float* target,
+                                           int32_t* pixel_idx, void* stream) {
+    if (!cams || !images || !state || !ray_batch || !target || R <= 0 || n_views <= 0 || image_stride <= 0)
+        NK_FAIL(NK_ERR_ARG, "nk_sample_training_rays_dev: null pointer or non-positive size");
+    if (channels != 3 && channels != 4)
+        NK_FAIL(NK_ERR_ARG, "nk_sample_training_rays_dev: %d channels (3 or 4)", channels);
+    hipLaunchKernelGGL(k_sample_training_rays_dev, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, nk_stream(stream),
+                       cams, images, image_stride, channels, white_background, state, R, ray_batch, target, pixel_idx);
+    NK_CHECK_LAUNCH("k_sample_training_rays_dev");
+    return NK_OK;
+}
+
 extern "C" int nk_get_rays(const nk_camera* cam, const int32_t* pixel_idx, int64_t first_pixel,
                            int64_t R, float* ray_batch, void* stream) {
     if (!cam || !ray_batch || R <= 0) NK_FAIL(NK_ERR_ARG, "nk_get_rays: null pointer or R <= 0");
@@ -98,7 +133,8 @@ extern "C" int nk_sample_training_rays(const nk_camera* cam, const uint8_t* imag
 // stratified depths: one thread per (ray, sample)
 // ============================================================================================
 __global__ void k_stratified_z(const float* __restrict__ rb, int64_t R, int Nc, int perturb, int lindisp,
-                               uint32_t seed, float* __restrict__ z) {
+                               uint32_t seed, const nk_step_state* __restrict__ st, float* __restrict__ z) {
+    if (st) seed = st->render_seed;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= R * Nc) return;
     const int64_t r = e / Nc;
@@ -124,7 +160,7 @@ extern "C" int nk_stratified_z(const float* ray_batch, int64_t R, const nk_rende
     if (o->num_coarse < 2) NK_FAIL(NK_ERR_ARG, "nk_stratified_z: num_coarse=%d < 2", o->num_coarse);
     const int64_t total = R * o->num_coarse;
     hipLaunchKernelGGL(k_stratified_z, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nk_stream(stream),
-                       ray_batch, R, o->num_coarse, o->perturb, o->lindisp, o->seed, z);
+                       ray_batch, R, o->num_coarse, o->perturb, o->lindisp, o->seed, o->state, z);
     NK_CHECK_LAUNCH("k_stratified_z");
     return NK_OK;
 }
@@ -140,9 +176,10 @@ NK_D float wave_sum(float v) {
 template <int M>
 __global__ __launch_bounds__(256) void k_composite_fwd(
     const float4* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rb, int64_t R, int n,
-    float noise_std, uint32_t seed, int noise_stream, int white,
+    float noise_std, uint32_t seed, const nk_step_state* __restrict__ st, int noise_stream, int white,
     float* __restrict__ rgb, float* __restrict__ disp, float* __restrict__ accm, float* __restrict__ depth,
     float* __restrict__ weights) {
+    if (st) seed = st->render_seed;
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= R) return;   // wave-uniform
@@ -214,7 +251,7 @@ extern "C" int nk_raw2outputs(const float* raw, const float* z, const float* ray
     if (M < 0) NK_FAIL(NK_ERR_UNSUPPORTED, "nk_raw2outputs: %d samples per ray (max 512)", n);
     const dim3 grid((unsigned)((R + 3) / 4)), block(256);
 #define NK_LAUNCH_CF(MM) hipLaunchKernelGGL(k_composite_fwd<MM>, grid, block, 0, nk_stream(stream), \
-        (const float4*)raw, z, ray_batch, R, (int)n, o->radiance_field_noise_std, o->seed, (int)noise_stream, \
+        (const float4*)raw, z, ray_batch, R, (int)n, o->radiance_field_noise_std, o->seed, o->state, (int)noise_stream, \
         (int)o->white_background, rgb, disp, acc, depth, weights)
     switch (M) { case 1: NK_LAUNCH_CF(1); break; case 2: NK_LAUNCH_CF(2); break; case 3: NK_LAUNCH_CF(3); break;
                  case 4: NK_LAUNCH_CF(4); break; default: NK_LAUNCH_CF(8); break; }
@@ -227,9 +264,10 @@ extern "C" int nk_raw2outputs(const float* raw, const float* z, const float* ray
 template <int M>
 __global__ __launch_bounds__(256) void k_composite_bwd(
     const float4* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rb, int64_t R, int n,
-    float noise_std, uint32_t seed, int noise_stream, int white,
+    float noise_std, uint32_t seed, const nk_step_state* __restrict__ st, int noise_stream, int white,
     const float* __restrict__ d_rgb, const float* __restrict__ d_acc, const float* __restrict__ d_depth,
     float4* __restrict__ d_raw) {
+    if (st) seed = st->render_seed;
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= R) return;
@@ -311,7 +349,7 @@ extern "C" int nk_raw2outputs_bwd(const float* raw, const float* z, const float*
     if (M < 0) NK_FAIL(NK_ERR_UNSUPPORTED, "nk_raw2outputs_bwd: %d samples per ray (max 512)", n);
     const dim3 grid((unsigned)((R + 3) / 4)), block(256);
 #define NK_LAUNCH_CB(MM) hipLaunchKernelGGL(k_composite_bwd<MM>, grid, block, 0, nk_stream(stream), \
-        (const float4*)raw, z, ray_batch, R, (int)n, o->radiance_field_noise_std, o->seed, (int)noise_stream, \
+        (const float4*)raw, z, ray_batch, R, (int)n, o->radiance_field_noise_std, o->seed, o->state, (int)noise_stream, \
         (int)o->white_background, d_rgb, d_acc, d_depth, (float4*)d_raw)
     switch (M) { case 1: NK_LAUNCH_CB(1); break; case 2: NK_LAUNCH_CB(2); break; case 3: NK_LAUNCH_CB(3); break;
                  case 4: NK_LAUNCH_CB(4); break; default: NK_LAUNCH_CB(8); break; }
@@ -327,7 +365,8 @@ enum { PDF_MAX_NC = 256, PDF_MAX_N = 512 };
 
 __global__ __launch_bounds__(256) void k_sample_pdf(
     const float* __restrict__ zc, const float* __restrict__ wts, int64_t R, int Nc, int Nf, int NP, int perturb,
-    uint32_t seed, float* __restrict__ z_all, float* __restrict__ z_samples) {
+    uint32_t seed, const nk_step_state* __restrict__ st, float* __restrict__ z_all, float* __restrict__ z_samples) {
+    if (st) seed = st->render_seed;
     __shared__ float s_cdf[4][PDF_MAX_NC];
     __shared__ float s_bins[4][PDF_MAX_NC];
     __shared__ float s_z[4][PDF_MAX_N];
@@ -413,7 +452,7 @@ extern "C" int nk_sample_pdf(const float* z_coarse, const float* weights, int64_
     int NP = 2;
     while (NP < Nc + Nf) NP <<= 1;
     hipLaunchKernelGGL(k_sample_pdf, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, nk_stream(stream),
-                       z_coarse, weights, R, Nc, Nf, NP, (int)o->perturb, o->seed, z_all, z_samples);
+                       z_coarse, weights, R, Nc, Nf, NP, (int)o->perturb, o->seed, o->state, z_all, z_samples);
     NK_CHECK_LAUNCH("k_sample_pdf");
     return NK_OK;
 }
@@ -451,7 +490,9 @@ extern "C" int nk_mse_loss(const float* rgb_coarse, const float* rgb_fine, const
 
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, int64_t n, float omb1, float b2, float omb2,
-                                              float eps, float step_size, float bc2_sqrt, float gscale) {
+                                              float eps, float step_size, float bc2_sqrt, float gscale,
+                                              const nk_step_state* __restrict__ st) {
+    if (st) { step_size = st->adam_step_size; bc2_sqrt = st->adam_bc2_sqrt; }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = m[i] + omb1 * (gi - m[i]);                   // exp_avg.lerp_(grad, 1 - beta1)
@@ -472,7 +513,28 @@ extern "C" int nk_adam_step(float* params, const float* grad, float* exp_avg, fl
     const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, nk_stream(stream), params, grad, exp_avg, exp_avg_sq, n,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(lr / bc1),
-                       (float)sqrt(bc2), grad_scale);
+                       (float)sqrt(bc2), grad_scale, (const nk_step_state*)nullptr);
+    NK_CHECK_LAUNCH("k_adam");
+    return NK_OK;
+}
+
+__global__ void k_set_step_state(nk_step_state v, nk_step_state* __restrict__ dst) { *dst = v; }
+
+extern "C" int nk_set_step_state(const nk_step_state* state_host, nk_step_state* state_dev, void* stream) {
+    if (!state_host || !state_dev) NK_FAIL(NK_ERR_ARG, "nk_set_step_state: null pointer");
+    hipLaunchKernelGGL(k_set_step_state, dim3(1), dim3(1), 0, nk_stream(stream), *state_host, state_dev);
+    NK_CHECK_LAUNCH("k_set_step_state");
+    return NK_OK;
+}
+
+extern "C" int nk_adam_step_dev(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                const nk_step_state* state, double beta1, double beta2, double eps, float grad_scale,
+                                void* stream) {
+    if (!params || !grad || !exp_avg || !exp_avg_sq || !state || n <= 0)
+        NK_FAIL(NK_ERR_ARG, "nk_adam_step_dev: null pointer or n <= 0");
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, nk_stream(stream), params, grad, exp_avg, exp_avg_sq, n,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, 0.0f, 1.0f, grad_scale, state);
     NK_CHECK_LAUNCH("k_adam");
     return NK_OK;
 }

@@ -26,10 +26,17 @@ class NkArch(C.Structure):
                                          "relu_first", "relu_feat", "lineage")]
 
 
+class NkStepState(C.Structure):
+    """Per-iteration scalars of a training step, read by the kernels from device memory (graph replay)."""
+    _fields_ = [("render_seed", C.c_uint32), ("pixel_seed", C.c_uint32), ("pixel_counter", C.c_uint64),
+                ("view", C.c_int32), ("adam_step_size", C.c_float), ("adam_bc2_sqrt", C.c_float), ("reserved", C.c_int32)]
+
+
 class NkRenderOpts(C.Structure):
     _fields_ = [("num_coarse", C.c_int32), ("num_fine", C.c_int32), ("perturb", C.c_int32),
                 ("lindisp", C.c_int32), ("white_background", C.c_int32),
-                ("radiance_field_noise_std", C.c_float), ("seed", C.c_uint32)]
+                ("radiance_field_noise_std", C.c_float), ("seed", C.c_uint32), ("reserved", C.c_int32),
+                ("state", C.c_void_p)]
 
 
 class NkCamera(C.Structure):
@@ -54,6 +61,9 @@ SIGNATURES = {
     "nk_pack_weights": (C.c_int, [_PA, _P, _P, _P]),
     "nk_get_rays": (C.c_int, [_PC, _P, _I64, _I64, _P, _P]),
     "nk_sample_training_rays": (C.c_int, [_PC, _P, _I32, _I32, C.c_uint32, C.c_uint64, _I64, _P, _P, _P, _P]),
+    "nk_sample_training_rays_dev": (C.c_int, [_P, _I32, _P, _I64, _I32, _I32, _P, _I64, _P, _P, _P, _P]),
+    "nk_set_step_state": (C.c_int, [C.POINTER(NkStepState), _P, _P]),
+    "nk_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I64, _P, C.c_double, C.c_double, C.c_double, _F, _P]),
     "nk_stratified_z": (C.c_int, [_P, _I64, _PO, _P, _P]),
     "nk_act_bytes": (_I64, [_PA, _I64, _I32]),
     "nk_mlp_forward": (C.c_int, [_PA, _P, _P, _P, _I64, _I32, _P, _P, _P]),

@@ -44,6 +44,8 @@ def parse_args(argv=None):
     ap.add_argument("--rays", type=int, default=None, help="override nerf.train.num_random_rays (per GPU)")
     ap.add_argument("--logdir", default=None, help="override experiment.logdir")
     ap.add_argument("--device", default=None, help="cuda:N (default: LOCAL_RANK)")
+    ap.add_argument("--graph", action="store_true",
+                    help="single GPU: replay the training iteration as one HIP graph (same results bit for bit)")
     return ap.parse_args(argv)
 
 
@@ -155,13 +157,22 @@ def main(argv=None) -> int:
         return 0
 
     sampler = RaySampler(scene, opts.num_random_rays, opts.seed, rank, world)
+    graphed = None
+    if a.graph:
+        if world > 1:
+            raise SystemExit("--graph: single-process training only")
+        from .trainer import GraphedStep
+        graphed = GraphedStep(tr, sampler)
     log = open(os.path.join(logdir, "log.jsonl"), "a") if rank == 0 else None
     iters = int(exp["train_iters"])
     t_last, it_last = time.perf_counter(), tr.iteration
     loss_val = float("nan")
     for i in range(tr.iteration, iters):
-        rb, target = sampler.next(i)
-        loss = tr.step(rb, target)
+        if graphed is not None:
+            loss = graphed.step()
+        else:
+            rb, target = sampler.next(i)
+            loss = tr.step(rb, target)
         last = i == iters - 1
         if rank == 0 and (i % int(exp["print_every"]) == 0 or last):
             loss_val = float(loss)            # the only host sync of the loop

@@ -250,6 +250,123 @@ class Trainer:
         return out
 
 
+class GraphedStep:
+    """The whole single-GPU training iteration -- pixel draw + get_rays + colours, render_rays
+    forward, img2mse, backward, Adam, re-pack of the weight images -- captured ONCE into a HIP graph
+    and replayed per iteration.  Everything that changes between iterations (seeds, pixel counter,
+    view index, Adam's two step-dependent scalars) lives in a 32-byte ``nk_step_state`` in device
+    memory that the kernels read when they run; per iteration the host queues one one-thread kernel
+    that carries the struct as its argument and one graph launch, instead of ~40 kernel launches.  At the
+    reference's own batch size (1 024 rays, 4x128 networks) the step is launch-bound, which is what
+    this removes.  Same kernels, same arithmetic as ``Trainer.step``: the two give the same bits.
+
+    ``capture=False`` issues the same launch sequence eagerly (what the graph is checked against)."""
+
+    def __init__(self, trainer: "Trainer", sampler, capture: bool = True):
+        import ctypes as C
+        if trainer.world != 1:
+            raise ValueError("GraphedStep: single-process training only (the all-reduce is not captured)")
+        sc = sampler.scene
+        if sampler.R != trainer.R:
+            raise ValueError(f"sampler draws {sampler.R} rays, trainer was sized for {trainer.R}")
+        self.tr, self.smp, self.L = trainer, sampler, trainer.L
+        dev = trainer.device
+        # camera table of every view and the image stack, on the device
+        cams = (_lib.NkCamera * sc.images.shape[0])(*[sc.camera(k) for k in range(sc.images.shape[0])])
+        self.cams = torch.frombuffer(bytearray(bytes(cams)), dtype=torch.uint8).to(dev)
+        self.n_views = int(sc.images.shape[0])
+        self.image_stride = int(sc.images.stride(0)) * sc.images.element_size()
+        self.channels = int(sc.images.shape[-1])
+        self.white = int(sc.white_background)
+        self._state = _lib.NkStepState()
+        self.state_dev = torch.zeros(C.sizeof(_lib.NkStepState), dtype=torch.uint8, device=dev)
+        o = trainer.ropts
+        self.ropts = _lib.NkRenderOpts(o.num_coarse, o.num_fine, o.perturb, o.lindisp, o.white_background,
+                                       o.radiance_field_noise_std, 0, 0, self.state_dev.data_ptr())
+        if trainer.ws is None:
+            trainer.ws = torch.empty(trainer.ws_bytes + 256, dtype=torch.uint8, device=dev)
+            trainer.ws_ptr = (trainer.ws.data_ptr() + 255) & ~255
+        self.graph = None
+        if capture:
+            # capture on a side stream; the launches only record (nothing runs, nothing is advanced)
+            self._fill_state()
+            _lib.check(self.L.nk_set_step_state(self._state, self.state_dev.data_ptr(), _stream(dev)))
+            torch.cuda.synchronize(dev)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                # one eager pass of the kernels first would advance the parameters, so instead the
+                # launch-time set-up that capture forbids (function attributes) is done by a throw-away
+                # pass on scratch copies of everything the step writes
+                keep = [t.clone() for t in (trainer.params, trainer.exp_avg, trainer.exp_avg_sq)]
+                self._launch(side.cuda_stream)
+                side.synchronize()
+                for t, k in zip((trainer.params, trainer.exp_avg, trainer.exp_avg_sq), keep):
+                    t.copy_(k)
+                trainer.coarse.pack()
+                if trainer.fine is not None:
+                    trainer.fine.pack()
+                side.synchronize()
+                with torch.cuda.graph(g, stream=side):
+                    self._launch(side.cuda_stream)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.graph = g
+
+    def _fill_state(self) -> None:
+        tr, smp, st = self.tr, self.smp, self._state
+        it = tr.iteration
+        st.render_seed = (tr.opts.seed + 0x9E3779B1 * (it + 1) + 7919 * tr._rank()) & 0xFFFFFFFF
+        st.pixel_seed = smp.seed
+        st.pixel_counter = smp.counter_of(it)
+        st.view = smp.view_of(it)
+        step = tr.opt_steps + 1
+        b1, b2 = tr.opts.betas
+        st.adam_step_size = lr_at(it, tr.opts) / (1.0 - b1 ** step)
+        st.adam_bc2_sqrt = math.sqrt(1.0 - b2 ** step)
+
+    def _launch(self, st: int) -> None:
+        """The launch sequence of one iteration on stream `st` (captured once, or issued eagerly)."""
+        tr, L, smp = self.tr, self.L, self.smp
+        R = tr.R
+        fc = tr.fine._c if tr.fine is not None else None
+        fp = tr.fine.packed.data_ptr() if tr.fine is not None else None
+        sp = self.state_dev.data_ptr()
+        _lib.check(L.nk_sample_training_rays_dev(self.cams.data_ptr(), self.n_views, smp.scene.images.data_ptr(),
+                                                 self.image_stride, self.channels, self.white, sp, R,
+                                                 smp.ray_batch.data_ptr(), smp.target.data_ptr(), smp.pixels.data_ptr(), st))
+        rb = smp.ray_batch.data_ptr()
+        _lib.check(L.nk_render_rays_fwd(tr.coarse._c, tr.coarse.packed.data_ptr(), fc, fp, rb, R, self.ropts, 1,
+                                        tr.ws_ptr, tr.ws_bytes, tr.out, st))
+        tr._grad_loss.zero_()
+        _lib.check(L.nk_mse_loss(tr.rgb_c.data_ptr(), _ptr(tr.rgb_f), smp.target.data_ptr(), R, 1.0, tr.loss.data_ptr(),
+                                 tr.d_rgb_c.data_ptr(), _ptr(tr.d_rgb_f), st))
+        gc, gf = tr.grad_views()
+        _lib.check(L.nk_render_rays_bwd(tr.coarse._c, tr.coarse.packed.data_ptr(), fc, fp, rb, R, self.ropts, tr.ws_ptr,
+                                        tr.ws_bytes, _ptr(tr.d_rgb_f), tr.d_rgb_c.data_ptr(), gc.data_ptr(), _ptr(gf), st))
+        _lib.check(L.nk_adam_step_dev(tr.params.data_ptr(), tr.grad.data_ptr(), tr.exp_avg.data_ptr(),
+                                      tr.exp_avg_sq.data_ptr(), tr.params.numel(), sp, tr.opts.betas[0], tr.opts.betas[1],
+                                      tr.opts.eps, 1.0, st))
+        for m in (tr.coarse, tr.fine):
+            if m is not None:
+                _lib.check(L.nk_pack_weights(m._c, m.flat.data_ptr(), m.packed.data_ptr(), st))
+
+    def step(self) -> torch.Tensor:
+        """One iteration (the trainer's next); returns the loss tensor (device, no sync)."""
+        tr = self.tr
+        dev = tr.device
+        with torch.cuda.device(dev):
+            self._fill_state()       # the struct goes to the device as a kernel argument: no host buffer to race with
+            _lib.check(self.L.nk_set_step_state(self._state, self.state_dev.data_ptr(), _stream(dev)))
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._launch(_stream(dev))
+        tr.iteration += 1
+        tr.opt_steps += 1
+        return tr.loss
+
+
 def _init_flat(arch: Arch, seed: int) -> torch.Tensor:
     """torch.nn.Linear default init, U(-1/sqrt(in), 1/sqrt(in)), in state-dict order."""
     g = torch.Generator().manual_seed(seed)

@@ -411,3 +411,35 @@ def test_wheel_capture_end_to_end(nk, tmp_path):
     assert train[-1]["loss"] < 0.5 * train[0]["loss"]
     assert val and all(v["view"] in (0, 8) for v in val)          # the held-out frames
     assert (tmp_path / "wheel" / "checkpoint00299.ckpt").is_file()
+
+
+def test_graph_step_equals_eager_step(nk, dev, teacher):
+    """GraphedStep (the iteration captured into a HIP graph, per-iteration scalars read from a
+    device-resident nk_step_state) against Trainer.step (scalars by value, one launch per kernel):
+    same rays, same loss, bit-identical gradient, parameters and Adam moments over six iterations;
+    and the eager issue of the device-state launch sequence gives the same again."""
+    from nerf_kinematics_amd.datasets import RaySampler
+    from nerf_kinematics_amd.trainer import GraphedStep
+    ref = _trainer(nk, dev, rays=512, seed=9)
+    smp_ref = RaySampler(teacher, 512, seed=3)
+    runs = []
+    for capture in (True, False):
+        tr = _trainer(nk, dev, rays=512, seed=9)
+        runs.append((tr, GraphedStep(tr, RaySampler(teacher, 512, seed=3), capture=capture)))
+    assert runs[0][1].graph is not None and runs[1][1].graph is None
+    for i in range(6):
+        rb, tgt = smp_ref.next(i)
+        l_ref = float(ref.step(rb, tgt))
+        for tr, gs in runs:
+            l = float(gs.step())
+            assert torch.equal(gs.smp.ray_batch, rb) and torch.equal(gs.smp.target, tgt)
+            assert abs(l - l_ref) <= 1e-6 * abs(l_ref)
+            assert torch.equal(tr.grad, ref.grad)
+            assert torch.equal(tr.params, ref.params)
+            assert torch.equal(tr.exp_avg, ref.exp_avg) and torch.equal(tr.exp_avg_sq, ref.exp_avg_sq)
+            assert tr.iteration == ref.iteration and tr.opt_steps == ref.opt_steps
+    assert float(ref.grad.abs().sum()) > 0
+    # the graph-trained networks render (weight images were re-packed inside the graph)
+    out = runs[0][0].render(rb[:64].contiguous())
+    out_ref = ref.render(rb[:64].contiguous())
+    assert torch.equal(out["rgb_fine"], out_ref["rgb_fine"])
