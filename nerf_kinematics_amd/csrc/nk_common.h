@@ -104,7 +104,8 @@ struct NkPlan {
     int n_params;
 };
 
-// Activation regions saved by the forward pass, each [G][width/8][32][8] bf16.
+// Activation regions saved by the forward pass, each [G][width/8][32][8] bf16 (the encodings in
+// slot order, the layer outputs with every 32-feature tile in nk_tile_feature() order).
 // index: 0 = gamma(x) slots (64), 1 = gamma(d) slots (32), 2+i = h_i (W), 2+D = feat (W), 3+D = g (WD)
 NK_HD int nk_act_width(const NkPlan& p, int idx) {
     if (idx == 0) return 64;
@@ -118,6 +119,14 @@ NK_HD int64_t nk_act_offset(const NkPlan& p, int idx, int64_t G) {   // bytes
     return feats * G * 64;      // 32 points * 2 bytes
 }
 NK_HD int nk_act_count(const NkPlan& p) { return p.D + 4; }
+
+// Feature (row of the 32-row tile) held at position x = 8 * octet + e of a saved activation / dZ
+// tile: the chain kernels store a converted accumulator fragment as it lies in registers (one
+// 16-byte store per fragment), which orders a tile's features this way rather than ascending.
+NK_HD int nk_tile_feature(int x) {
+    const int o = x >> 3, e = x & 7;
+    return 16 * (o >> 1) + 8 * (e >> 2) + 4 * (o & 1) + (e & 3);
+}
 
 // ReLU masks, one 16-byte word per lane per layer ([G][64 lanes][4 dwords]), stored after the
 // activation regions: idx 0..D-1 = h_i, D = feat, D+1 = g.  Bit 31 - (16*(t&1) + i) of dword t>>1

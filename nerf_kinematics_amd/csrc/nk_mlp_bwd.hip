@@ -36,6 +36,7 @@ struct GemmDst {
     int w_off, ld;                          // destination matrix origin and leading dimension
     int row_first, row_count, row_dst0;     // segment rows [row_first, +row_count) -> matrix rows row_dst0..
     int colmode, col_base, col_count, nfreq;
+    int row_tiled, col_tiled;               // rows / identity columns arrive in nk_tile_feature() order
 };
 
 // A and B are each one or two regions ([G][tiles*4][32][8] bf16) laid side by side, so that GEMMs
@@ -114,6 +115,8 @@ NK_D int64_t gemm_dst_index(const GemmArgs& a, int mt, int nt, int m_in_tile, in
     const int sa = mt >= a.MA0, sb = nt >= a.NB0;
     const GemmDst& d = a.dst[sa][sb];
     if (!d.enabled) return -1;
+    if (d.col_tiled && d.colmode == NK_COL_IDENT) r = nk_tile_feature(r);
+    if (d.row_tiled) m_in_tile = nk_tile_feature(m_in_tile);
     const int n = 32 * (nt - (sb ? a.NB0 : 0)) + r;         // column inside the B segment
     int dcol;
     if (d.colmode == NK_COL_IDENT) dcol = n < d.col_count ? d.col_base + n : -1;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void k_dw_reduce(GemmBatch batch, int MT, int 
             const int mt = b >> 5, r = b & 31;
             const int sa = mt >= a.MA0;
             const GemmDst& d = a.dst[sa][0];
-            const int mr = 32 * (mt - (sa ? a.MA0 : 0)) + r - d.row_first;
+            const int mr = 32 * (mt - (sa ? a.MA0 : 0)) + (d.row_tiled ? nk_tile_feature(r) : r) - d.row_first;
             if (a.b_off[sa] >= 0 && mr >= 0 && mr < d.row_count) dst = a.b_off[sa] + d.row_dst0 + mr;
             p = p0 + (int64_t)n_rows * 64 + mt * WN * 32 + r;
             terms = WN;
@@ -305,6 +308,7 @@ static GemmDst gemm_dst(int w_off, int ld, int row_first, int row_count, int col
     GemmDst d;
     d.enabled = 1; d.w_off = w_off; d.ld = ld; d.row_first = row_first; d.row_count = row_count; d.row_dst0 = 0;
     d.colmode = colmode; d.col_base = col_base; d.col_count = col_count; d.nfreq = nfreq;
+    d.row_tiled = 1; d.col_tiled = 1;       // dZ / activation tiles as the chain kernels store them
     return d;
 }
 
@@ -483,6 +487,7 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
     {   // rgb: rows 0..2 of dOut against g
         GemmDst d[2][2] = {};
         d[0][0] = gemm_dst(lrgb.w_off, lrgb.in_dim, 0, 3, NK_COL_IDENT, 0, WD, 0);
+        d[0][0].row_tiled = 0;              // the dOut tile keeps its rows in ascending order
         queue_gemm(q, dz(0), 32, nullptr, 0, act(3 + D), WD, nullptr, 0, G, grad, d, lrgb.b_off, -1);
     }
     {   // views: dZ_views against cat[feat, gamma(d)]
@@ -495,6 +500,7 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
         GemmDst d[2][2] = {};
         d[0][0] = gemm_dst(lfeat.w_off, lfeat.in_dim, 0, W, NK_COL_IDENT, 0, W, 0);
         d[1][0] = gemm_dst(lalpha.w_off, lalpha.in_dim, 3, 1, NK_COL_IDENT, 0, W, 0);
+        d[1][0].row_tiled = 0;              // (dOut tile)
         queue_gemm(q, dz(2), W, dz(0), 32, act(2 + D - 1), W, nullptr, 0, G, grad, d, lfeat.b_off, lalpha.b_off);
     }
     for (int L = D - 1; L >= 0; --L) {     // trunk
