@@ -187,7 +187,11 @@ NK_D f32x16 tile_run(f32x16 acc, const char* stage, int lane, const Frag* b0, co
         if constexpr (!__is_same(WS, void)) {       // one piece of the announced stream load every third k-step
             if (NK_DMA_SPREAD && ks % 3 == 1 && ks / 3 < 6) ws->piece(ks / 3);
         }
+#ifdef NK_PROBE_HALF_LDS      // (timing probe, wrong results: every other weight fragment is not read)
+        if (ks + LA < NK && (ks & 1)) {
+#else
         if (ks + LA < NK) {
+#endif
             a[ks % LA] = *(const bf16x8*)(base + (ks + LA) * 1024);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
