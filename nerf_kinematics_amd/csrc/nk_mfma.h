@@ -275,13 +275,35 @@ NK_D void acc_to_frags_mask(const f32x16& a, bool relu, Frag& f0, Frag& f1, uint
     acc_to_frags(a, relu, f0, f1);
 }
 
+// ReLU of two packed bf16 values in one instruction: v_pk_max_i16 against 0 on the bit patterns
+// (a negative bf16, -0 included, is a negative 16-bit integer).  Rounding to bf16 keeps the sign, so
+// this equals rounding max(x, 0) bit for bit, at half the instructions of a ReLU per fp32 value.
+// Measured SLOWER in the forward chain (inference 3.06 -> 3.23 ms: the max now waits on the
+// convert instead of running ahead of it), so it is off; kept as a switch.
+#ifndef NK_RELU_PACKED
+#define NK_RELU_PACKED 0
+#endif
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+NK_D uint32_t relu_pk_bf16(uint32_t p) {
+    s16x2 v = __builtin_bit_cast(s16x2, p);
+    v = __builtin_elementwise_max(v, s16x2{0, 0});
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         float x0 = a[2 * w], x1 = a[2 * w + 1], y0 = a[8 + 2 * w], y1 = a[8 + 2 * w + 1];
+#if NK_RELU_PACKED
+        uint32_t p0 = pack_bf16(x0, x1), p1 = pack_bf16(y0, y1);
+        if (relu) { p0 = relu_pk_bf16(p0); p1 = relu_pk_bf16(p1); }
+        f0.u[w] = p0;
+        f1.u[w] = p1;
+#else
         if (relu) { x0 = relu1(x0); x1 = relu1(x1); y0 = relu1(y0); y1 = relu1(y1); }
         f0.u[w] = pack_bf16(x0, x1);
         f1.u[w] = pack_bf16(y0, y1);
+#endif
     }
 }
 
