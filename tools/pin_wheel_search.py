@@ -128,6 +128,20 @@ def main():
                     c, p, tr = score(ps, focal)
                     rows.append((c, p, tr[0], f"{ax} recenter={rc} scale={s:.5f} f={focal:.1f}"))
                     print(f"corr {c:+.3f} psnr {p:5.2f} | pose 1 vs photo {tr[1]:2d}: {tr[0]:5.2f} dB | {rows[-1][3]}", flush=True)
+        print("# grid 3: every signed permutation of the camera axes (48) x pose as given / inverted x LLFF recentring x 5 scales, f = fl_x/8")
+        for perm in itertools.permutations(range(3)):
+            for signs in itertools.product((1, -1), repeat=3):
+                b = np.zeros((3, 3))
+                for j, (pj, sg) in enumerate(zip(perm, signs)):
+                    b[pj, j] = sg                      # new camera axis j = sg * old axis pj
+                for inv in (False, True):
+                    base = np.linalg.inv(raw) if inv else raw.copy()
+                    ps0 = base.copy(); ps0[:, :3, :3] = base[:, :3, :3] @ b
+                    for s in (0.001, 0.03, 0.3, 1.0, 3.0):
+                        ps = ps0.copy(); ps[:, :3, 3] *= s; ps = recenter(ps)
+                        c, p, tr = score(ps, FX)
+                        rows.append((c, p, tr[0], f"axes {perm} signs {signs} inverted={inv} scale={s}"))
+                        print(f"corr {c:+.3f} psnr {p:5.2f} | pose 1 vs photo {tr[1]:2d}: {tr[0]:5.2f} dB | {rows[-1][3]}", flush=True)
     rows = [r for r in rows if r[0] == r[0]]
     print("# best by correlation with the reference render")
     for r in sorted(rows)[-8:]:
