@@ -158,3 +158,32 @@ def test_wheel_capture_1280x720(nk, golden_dir, tmp_path):
     # (the wheel field is an over-fitted, near-saturated function of position: bf16 operand rounding
     # moves its renders about four times as much as the lego field's, hence the wider mean bound)
     _subset_vs_oracle(nk, scene, k, rb, coarse, fine, O.ARCH_WHEEL_CKPT, wc, wf, dev, mean_tol=8e-3)
+
+
+def test_lego_800x800_single_gpu(nk, golden_dir):
+    """The full-resolution lego configuration (800 x 800; meant to be sharded over 8 GPUs) on ONE
+    GPU: the whole frame rendered with the reference's trained lego networks -- chunk invariance,
+    bounds, seed determinism over all 640 000 rays, the oracle on a ray subset -- and the row-block
+    sharding arithmetic that splits such a frame over 8 ranks."""
+    import math
+    from nerf_kinematics_amd import datasets, dist as nd
+    dev = torch.device("cuda:0")
+    focal = 0.5 * 800 / math.tan(0.5 * datasets.LEGO_CAMERA_ANGLE_X)
+    scene = datasets.Scene(None, datasets.spherical_pose(45.0, -30.0, 4.0)[None], 800, 800, focal, focal, 400.0, 400.0, 2.0, 6.0)
+    w = np.load(os.path.join(golden_dir, "lego_lowres3_weights.npz"))
+    wc, wf = torch.from_numpy(w["coarse"]), torch.from_numpy(w["fine"])
+    coarse, fine = nk.NeRFModel(nk.ARCH_LEGO_CKPT, wc.to(dev)), nk.NeRFModel(nk.ARCH_LEGO_CKPT, wf.to(dev))
+    rb = scene.rays(0, dev)
+    assert rb.shape == (640000, 11)
+    kw = dict(num_coarse=64, num_fine=128)
+    with torch.no_grad():
+        full = torch.cat([nk.render_rays(rb[s:s + 131072], coarse, fine, **kw)[0] for s in range(0, 640000, 131072)])
+        # the eight row blocks an 8-rank job would render, each on its own, concatenated
+        blocks = [nd.row_block(640000, r, 8) for r in range(8)]
+        assert blocks[0] == slice(0, 80000) and blocks[7] == slice(560000, 640000)
+        sharded = torch.cat([nk.render_rays(rb[b].contiguous(), coarse, fine, **kw)[0] for b in blocks])
+    assert torch.equal(full, sharded)
+    assert torch.isfinite(full).all() and float(full.min()) >= 0.0 and float(full.max()) <= 1.0 + 1e-5
+    img = full.reshape(800, 800, 3)
+    assert float(img[350:450, 350:450].mean()) > 0.05 and float(img[:40, :40].mean()) < 0.02     # object in the middle, (nearly) empty corner
+    _subset_vs_oracle(nk, scene, 0, rb, coarse, fine, O.ARCH_LEGO_CKPT, wc, wf, dev, n=512)
