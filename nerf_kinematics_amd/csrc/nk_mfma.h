@@ -137,14 +137,22 @@ struct WStream {
     // the true count only waits longer; a larger one would race.
     template <int N>
     NK_D void flip_keep() {
+#ifdef NK_PROBE_NO_BARRIER     // (timing probe, wrong results: stages are not synchronised across the workgroup)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
         advance();
     }
     // Same, naming the tile's accumulator: its MFMAs are register-only instructions that hipcc
     // otherwise sinks below the barrier, stretching the live range of 16 weight fragments.
     template <int N>
     NK_D void flip_keep(f32x16& acc) {
+#ifdef NK_PROBE_NO_BARRIER
+        asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)" : "+v"(acc) : "n"(N) : "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)\n\ts_barrier" : "+v"(acc) : "n"(N) : "memory");
+#endif
         advance();
     }
     NK_D const char* stage() const { return ring + cur * slot_bytes; }
@@ -291,6 +299,10 @@ NK_D uint32_t relu_pk_bf16(uint32_t p) {
 }
 
 NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1) {
+#ifdef NK_PROBE_NO_CONVERT      // (timing probe, wrong results: accumulator bits passed on unconverted)
+    for (int w = 0; w < 4; ++w) { f0.u[w] = (uint32_t)__float_as_int(a[w]); f1.u[w] = (uint32_t)__float_as_int(a[8 + w]); }
+    return;
+#endif
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         float x0 = a[2 * w], x1 = a[2 * w + 1], y0 = a[8 + 2 * w], y1 = a[8 + 2 * w + 1];

@@ -224,3 +224,19 @@ def test_gradient_distance_to_the_fp32_oracle(nk, dev):
                 print(f"    {pname}.{kind:6s} share {share:6.3f}  rel L2 {tr_rel:.4f}  cosine {tr_cos:.5f}")
                 if share > 0.01:
                     assert tr_rel < 0.16 and tr_cos > 0.99, (name, pname, kind, tr_rel, tr_cos)
+
+
+def test_tuning_switches_keep_parity():
+    """The kernel variants behind the environment switches (8 forward waves with the staggered
+    stage order, 4 backward waves without it) pass the same forward and gradient checks: the
+    switches are read once per process, so the checks run in a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NK_WAVES_FWD="8", NK_STAGGER_FWD="1", NK_WAVES_BWD="4", NK_STAGGER_BWD="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_backward.py"), os.path.join(root, "tests", "test_gpu_parity.py"),
+                        "-k", "mlp_backward_matches_autograd or render_rays_gradients or mlp_forward or golden"],
+                       env=env, capture_output=True, text=True, timeout=160, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout
