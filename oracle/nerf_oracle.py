@@ -34,7 +34,11 @@ only one combination of conventions (no ReLU after ``layer1``, ReLU on ``fc_feat
 checkpoint as a coherent object: opaque centre, empty corners, mean colour about
 (0.18, 0.15, 0.10).  ``tests/test_oracle.py`` asserts exactly that on the weights extracted to
 ``tests/golden/``.  ``ndc_rays`` and the 8x256 ``run_nerf`` architecture have no such pin:
-parity unpinned for those (they follow the paper).
+parity unpinned for those (they follow the paper).  The reference's one rendered nerf-pytorch image
+of its robot capture (``/root/reference/results/wheel/nerf-pytorch/imgs/rendered/TestNERF_0_original_gen.png``
+with its target under ``imgs/reals/``) pins the loader's held-out view and image reduction
+(``tests/test_wheel_pin.py``) but not this file: a bounded search over camera conventions
+(``tools/pin_wheel_search.py``) did not reproduce that render from the vendored wheel weights.
 
 Random numbers
 --------------
