@@ -328,6 +328,13 @@ def test_run_nerf_cli_trains_saves_resumes_and_renders(nk, tmp_path):
     r = run("--load-checkpoint", str(out / "checkpoint00049.ckpt"), "--render-only", "--render-poses", str(path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rendered 4 frames" in r.stdout
+    # the same run with the iteration replayed as a HIP graph writes the same checkpoint
+    r = run("--graph", "--logdir", str(tmp_path / "g"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ckg = torch.load(tmp_path / "g" / "cli" / "checkpoint00039.ckpt", map_location="cpu", weights_only=True)
+    for k, v in ck["model_fine_state_dict"].items():
+        assert torch.equal(v, ckg["model_fine_state_dict"][k]), k
+    assert torch.equal(ck["optimizer_state_dict"]["state"][3]["exp_avg_sq"], ckg["optimizer_state_dict"]["state"][3]["exp_avg_sq"])
 
 
 def test_run_nerf_cli_two_ranks(nk, tmp_path):
