@@ -286,8 +286,9 @@ NK_D void acc_to_frags_mask(const f32x16& a, bool relu, Frag& f0, Frag& f1, uint
 // ReLU of two packed bf16 values in one instruction: v_pk_max_i16 against 0 on the bit patterns
 // (a negative bf16, -0 included, is a negative 16-bit integer).  Rounding to bf16 keeps the sign, so
 // this equals rounding max(x, 0) bit for bit, at half the instructions of a ReLU per fp32 value.
-// Measured SLOWER in the forward chain (inference 3.06 -> 3.23 ms: the max now waits on the
-// convert instead of running ahead of it), so it is off; kept as a switch.
+// Measured: slower when each max directly follows its convert (inference 3.06 -> 3.23 ms), and
+// within 0.3 % of the fp32 form (19.19 vs 19.25 ms per training step) with all converts issued
+// first, so it stays off; kept as a switch.
 #ifndef NK_RELU_PACKED
 #define NK_RELU_PACKED 0
 #endif
@@ -303,19 +304,26 @@ NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1) {
     for (int w = 0; w < 4; ++w) { f0.u[w] = (uint32_t)__float_as_int(a[w]); f1.u[w] = (uint32_t)__float_as_int(a[8 + w]); }
     return;
 #endif
+#if NK_RELU_PACKED
+    // all eight converts first, then the eight packed maxima: no instruction waits on its neighbour
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        f0.u[w] = pack_bf16(a[2 * w], a[2 * w + 1]);
+        f1.u[w] = pack_bf16(a[8 + 2 * w], a[8 + 2 * w + 1]);
+    }
+    if (relu) {
+        asm volatile("" : "+v"(f0.u), "+v"(f1.u));
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { f0.u[w] = relu_pk_bf16(f0.u[w]); f1.u[w] = relu_pk_bf16(f1.u[w]); }
+    }
+#else
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         float x0 = a[2 * w], x1 = a[2 * w + 1], y0 = a[8 + 2 * w], y1 = a[8 + 2 * w + 1];
-#if NK_RELU_PACKED
-        uint32_t p0 = pack_bf16(x0, x1), p1 = pack_bf16(y0, y1);
-        if (relu) { p0 = relu_pk_bf16(p0); p1 = relu_pk_bf16(p1); }
-        f0.u[w] = p0;
-        f1.u[w] = p1;
-#else
         if (relu) { x0 = relu1(x0); x1 = relu1(x1); y0 = relu1(y0); y1 = relu1(y1); }
         f0.u[w] = pack_bf16(x0, x1);
         f1.u[w] = pack_bf16(y0, y1);
-#endif
     }
+#endif
 }
 
