@@ -6,6 +6,8 @@
 // Saved tensors all use one layout, [group of 32 points][feature octet][point][8 features] bf16,
 // which is what a wavefront's converted accumulators store with 8-byte pieces and what
 // ds_read_b64_tr_b16 turns into MFMA operands whose k index runs over points.
+#include <stdio.h>
+#include <string.h>
 #include "nk_common.h"
 #include "nk_mfma.h"
 
@@ -41,16 +43,29 @@ struct GemmDst {
 
 // A and B are each one or two regions ([G][tiles*4][32][8] bf16) laid side by side, so that GEMMs
 // sharing an operand (a skip layer's two inputs, the view layer's two inputs) read it from HBM
-// once.
-struct GemmArgs {
-    const char* A[2]; int MA0;      // A tiles [0, MA0) come from A[0], the rest from A[1]
-    const char* B[2]; int NB0;
+// once.  What the product kernel needs of one product:
+struct GemmSrc {
+    const char* A[2];               // A tiles [0, MA0) come from A[0], the rest from A[1]
+    const char* B[2];
     int64_t n_stages;               // G (a stage = 1 group = 32 points)
-    int64_t stages_per_wg;
+    int64_t partial_off;            // first float of this product's slices in the partial-sum scratch
+    int stages_per_wg;              // K-slice length of this product in this launch
     int wg_begin;                   // first workgroup of this product in the launch's 1-D grid
-    float* grad;                    // flat gradient
+    // (32-bit fields only: a 16-bit one is fetched with a VECTOR load, and the wait for it inside
+    // the stage loop would drain the whole load pipeline)
+    int MA0, NB0;
+    int shape;                      // index into NK_GEMM_SHAPES
+    int want_bias;
+};
+// ... and what the reduction needs: where the sums go.
+struct GemmOut {
     GemmDst dst[2][2];              // [A segment][B segment]
     int b_off[2];                   // bias gradient origin per A segment (rows as dst[seg][0]), or -1
+    int MA0, NB0;
+    int mt, nt, wn;                 // tile counts of the product and waves across a tile row
+    int n_slices;
+    int64_t partial_off;
+    float* grad;                    // flat gradient
 };
 
 // Transposed LDS reads are issued from inline asm: hipcc drains vmcnt before a
@@ -94,24 +109,40 @@ NK_D void gemm_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// Up to NK_GEMM_BATCH products of one shape per launch.  The launch is ONE round of workgroups
-// over the chip: the points of all its products are cut into equal K-slices, one per workgroup
-// (product k owns workgroups [wg_begin_k, wg_begin_{k+1})), so every CU streams the same number of
-// bytes.  A workgroup does not add its K-slice into the gradient (device-scope fp32 atomics on
-// one 256-KiB matrix run at ~0.6 TB/s chip-wide): it stores its accumulator tiles to its own
-// slice of a scratch region with plain coalesced stores, and k_dw_reduce sums the slices of each
-// product in a fixed order and adds the result to the gradient, which also makes the gradient
-// bit-reproducible from run to run.
+// ONE launch runs every weight-gradient product of a network (of both networks when the batch
+// is small), whatever their shapes: the launch is one round of workgroups over the chip, the
+// points of each product are cut into K-slices of about equal BYTES, one per workgroup (product k
+// owns workgroups [wg_begin_k, wg_begin_{k+1})), and a workgroup branches once into the body
+// compiled for its product's tile shape.  A workgroup does not add its K-slice into the gradient
+// (device-scope fp32 atomics on one 256-KiB matrix run at ~0.6 TB/s chip-wide): it stores its
+// accumulator tiles to its own slice of a scratch region with plain coalesced stores, and
+// k_dw_reduce sums the slices of each product in a fixed order and adds the result to the
+// gradient, which also makes the gradient bit-reproducible from run to run.
 //   slice layout (floats): [MT*NT tiles][16 accumulator registers][64 lanes], then the bias
 //   partial sums [MT][WN][32].
-enum { NK_GEMM_BATCH = 8 };
-struct GemmBatch { GemmArgs g[NK_GEMM_BATCH]; int count; float* partial; };
+enum { NK_GEMM_MAX_PRODUCTS = 24, NK_REDUCE_BATCH = 12 };
+struct GemmBatch { GemmSrc g[NK_GEMM_MAX_PRODUCTS]; float* partial; int count; };
+struct ReduceBatch { GemmOut g[NK_REDUCE_BATCH]; const float* partial; };
+
+// (A tiles, B tiles, waves down, waves across, ns per stage) of every product the supported
+// networks produce.  The last column is what the K-slices of a launch are balanced with: the
+// measured time of one stage (32 points) when every CU runs that shape (NK_GEMM_PER_SHAPE=1
+// launches the shapes one by one; NK_GEMM_COSTS="id:ns,..." overrides entries).  The thinnest
+// product (1 x 2 tiles, 6 KB per stage) is latency-bound and slows down next to bandwidth-bound
+// neighbours: it is entered a third above its stand-alone 713 ns.
+//   width 256: trunk, trunk 0, rgb, feature + alpha, skip (h + gamma(x)), views (feat + gamma(d))
+//   width 128: the same six
+#define NK_GEMM_SHAPES(X) \
+    X(0, 8, 8, 2, 4, 1455) X(1, 8, 2, 4, 2, 921) X(2, 1, 4, 1, 4, 571) X(3, 9, 8, 1, 8, 1589) \
+    X(4, 8, 10, 4, 2, 1669) X(5, 4, 9, 2, 3, 1148) \
+    X(6, 4, 4, 2, 4, 694) X(7, 4, 2, 4, 2, 601) X(8, 1, 2, 1, 2, 950) X(9, 5, 4, 1, 4, 831) \
+    X(10, 4, 6, 2, 2, 900) X(11, 2, 5, 2, 1, 673)
 
 NK_HD int64_t gemm_slice_floats(int MT, int NT, int WN) { return (int64_t)MT * NT * 1024 + (int64_t)MT * WN * 32; }
 
 // Flat gradient index that element (row m of A tile mt, column n-in-tile r of B tile nt) of a
 // product accumulates into, or -1 (padding rows / columns, disabled segment pairs).
-NK_D int64_t gemm_dst_index(const GemmArgs& a, int mt, int nt, int m_in_tile, int r) {
+NK_D int64_t gemm_dst_index(const GemmOut& a, int mt, int nt, int m_in_tile, int r) {
     const int sa = mt >= a.MA0, sb = nt >= a.NB0;
     const GemmDst& d = a.dst[sa][sb];
     if (!d.enabled) return -1;
@@ -133,13 +164,9 @@ NK_D int64_t gemm_dst_index(const GemmArgs& a, int mt, int nt, int m_in_tile, in
 }
 
 template <int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
-    int prod = 0;
-    while (prod + 1 < batch.count && (int)blockIdx.x >= batch.g[prod + 1].wg_begin) ++prod;
-    const GemmArgs& a = batch.g[prod];
+NK_D void gemm_body(const GemmSrc& a, float* slice, char* lds) {
     constexpr int TM = MT / WM, TN = NT / WN;       // wave tile, in 32x32 tiles
     static_assert(TM * WM == MT && TN * WN == NT && WM * WN <= 8, "wave grid must tile the output");
-    extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int stage_bytes = (MT + NT) * 2048;       // one group's A piece then B piece
@@ -180,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) bsum[i] = 0.0f;
     bf16x2 ones; ones[0] = (__bf16)1.0f; ones[1] = (__bf16)1.0f;
-    const bool want_bias = a.b_off[0] >= 0 || a.b_off[1] >= 0;
+    const bool want_bias = a.want_bias != 0;
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)(NK_LDS char*)lds;
     for (int64_t s = s0; s < s0 + 3 && s < s1; ++s) issue(s);
@@ -234,7 +261,6 @@ __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
     }
     if (!active) return;
     // epilogue: this K-slice's tiles to the workgroup's scratch slice (256 B per store instruction)
-    float* slice = batch.partial + (int64_t)blockIdx.x * gemm_slice_floats(MT, NT, WN);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -252,19 +278,36 @@ __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
     }
 }
 
+__global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int prod = 0;
+    while (prod + 1 < batch.count && (int)blockIdx.x >= batch.g[prod + 1].wg_begin) ++prod;
+    const GemmSrc& a = batch.g[prod];
+    const int wg = (int)blockIdx.x - a.wg_begin;
+    switch (a.shape) {
+#define NK_GEMM_CASE(ID, MT, NT, WM, WN, NS) \
+    case ID: gemm_body<MT, NT, WM, WN>(a, batch.partial + a.partial_off + (int64_t)wg * gemm_slice_floats(MT, NT, WN), lds); break;
+        NK_GEMM_SHAPES(NK_GEMM_CASE)
+#undef NK_GEMM_CASE
+    default: break;
+    }
+}
+
 // Second stage: sums every output element of a product over the product's slices and adds it to
 // the flat gradient.  A workgroup owns 64 consecutive elements (one accumulator register of one
 // tile); its four wavefronts take the slices w = 0, 1, 2, 3 (mod 4) with eight loads in flight
-// each and meet in LDS, so the order of the additions is fixed.  blockIdx.y = product; the last
-// workgroups of a product do the bias rows.
-__global__ __launch_bounds__(256) void k_dw_reduce(GemmBatch batch, int MT, int NT, int WN) {
+// each and meet in LDS, so the order of the additions is fixed.  blockIdx.y = product (the grid
+// is as wide as the largest one needs); the last workgroups of a product do the bias rows.
+__global__ __launch_bounds__(256) void k_dw_reduce(ReduceBatch batch) {
     __shared__ float part[4][64];
-    const GemmArgs& a = batch.g[blockIdx.y];
+    const GemmOut& a = batch.g[blockIdx.y];
+    const int MT = a.mt, NT = a.nt, WN = a.wn;
     const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int n_rows = MT * NT * 16;                     // 64-element rows of the weight part
+    if ((int)blockIdx.x >= n_rows + (MT * 32 + 63) / 64) return;        // (uniform: before the barrier)
     const int64_t stride = gemm_slice_floats(MT, NT, WN);
-    const int n_slices = (int)((a.n_stages + a.stages_per_wg - 1) / a.stages_per_wg);
-    const float* p0 = batch.partial + (int64_t)a.wg_begin * stride;
+    const int n_slices = a.n_slices;
+    const float* p0 = batch.partial + a.partial_off;
     int64_t dst = -1;
     const float* p = nullptr;
     int terms = 1;                                       // values per slice that fold into the element
@@ -312,10 +355,10 @@ static GemmDst gemm_dst(int w_off, int ld, int row_first, int row_count, int col
     return d;
 }
 
-// Products queued by nk_mlp_backward, launched shape by shape.
+// Products queued by nk_mlp_backward_gemms for one launch.
 struct GemmQueue {
-    GemmArgs g[32];         // 12 products per network, two networks
-    int MT[32], NT[32];
+    GemmSrc src[NK_GEMM_MAX_PRODUCTS];
+    GemmOut out[NK_GEMM_MAX_PRODUCTS];
     int n = 0;
 };
 
@@ -323,16 +366,20 @@ struct GemmQueue {
 static void queue_gemm(GemmQueue& q, const char* A0, int wA0, const char* A1, int wA1, const char* B0, int wB0,
                        const char* B1, int wB1, int64_t G, float* grad, const GemmDst (&dst)[2][2], int b_off0,
                        int b_off1) {
-    GemmArgs& g = q.g[q.n];
+    GemmSrc& g = q.src[q.n];
+    GemmOut& o = q.out[q.n];
     g.A[0] = A0; g.A[1] = A1 ? A1 : A0; g.MA0 = wA0 / 32;
     g.B[0] = B0; g.B[1] = B1 ? B1 : B0; g.NB0 = wB0 / 32;
-    q.MT[q.n] = (wA0 + wA1) / 32; q.NT[q.n] = (wB0 + wB1) / 32;
-    for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2; ++j) g.dst[i][j] = dst[i][j];
-    g.b_off[0] = b_off0; g.b_off[1] = b_off1;
     g.n_stages = G;
-    g.stages_per_wg = 0; g.wg_begin = 0;      // set per launch (flush_gemms)
-    g.grad = grad;
+    g.partial_off = 0; g.stages_per_wg = 0; g.wg_begin = 0; g.shape = -1;     // set per launch (flush_gemms)
+    g.want_bias = (b_off0 >= 0 || b_off1 >= 0) ? 1 : 0;
+    o.mt = (wA0 + wA1) / 32; o.nt = (wB0 + wB1) / 32; o.wn = 0;
+    o.MA0 = g.MA0; o.NB0 = g.NB0;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) o.dst[i][j] = dst[i][j];
+    o.b_off[0] = b_off0; o.b_off[1] = b_off1;
+    o.n_slices = 0; o.partial_off = 0;
+    o.grad = grad;
     ++q.n;
 }
 
@@ -340,20 +387,20 @@ static void queue_gemm(GemmQueue& q, const char* A0, int wA0, const char* A1, in
 enum { NK_GEMM_MIN_STAGES = 6, NK_MAX_GPUS = 64 };
 static int gemm_wg_limit() {
     static const int env_wgs = []() { const char* e = getenv("NK_GEMM_WGS"); return e ? atoi(e) : 0; }();
-    if (env_wgs > 0) return env_wgs;
+    if (env_wgs > 0) return env_wgs < NK_GEMM_MAX_PRODUCTS ? NK_GEMM_MAX_PRODUCTS : env_wgs;
     static int cus[NK_MAX_GPUS];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NK_MAX_GPUS) return 256;
     if (!cus[dev]) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
+        cus[dev] = n < NK_GEMM_MAX_PRODUCTS ? NK_GEMM_MAX_PRODUCTS : n;
     }
     return cus[dev];
 }
 
-// Scratch for the K-slice partial sums of one launch: one slice per workgroup, sized for the
-// largest product shape of the network width.
+// Scratch for the K-slice partial sums of one launch: one slice per workgroup, so at most one
+// slice of the largest product shape of the network width per workgroup.
 static int64_t gemm_partial_bytes(int W) {
     // (MT, NT, WN) of the largest slice: skip layer (8,10,2) for width 256, (4,6,2) for width 128
     const int64_t f = W == 256 ? gemm_slice_floats(8, 10, 2) : gemm_slice_floats(4, 6, 2);
@@ -362,66 +409,92 @@ static int64_t gemm_partial_bytes(int W) {
 }
 
 static int flush_gemms(GemmQueue& q, float* partial, int64_t partial_bytes, hipStream_t stream) {
-    bool done[32] = {};
+    static const int shapes[][5] = {
+#define NK_GEMM_ROW(ID, MT, NT, WM, WN, NS) {MT, NT, WM, WN, NS},
+        NK_GEMM_SHAPES(NK_GEMM_ROW)
+#undef NK_GEMM_ROW
+    };
+    constexpr int n_shapes = (int)(sizeof(shapes) / sizeof(shapes[0]));
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NK_MAX_GPUS) dev = 0;
-    for (int first = 0; first < q.n; ++first) {
-        if (done[first]) continue;
-        const int MT = q.MT[first], NT = q.NT[first];
-        GemmBatch batch;
-        int count = 0;
-        for (int k = first; k < q.n && count < NK_GEMM_BATCH; ++k)
-            if (!done[k] && q.MT[k] == MT && q.NT[k] == NT) { batch.g[count++] = q.g[k]; done[k] = true; }
-        for (int k = count; k < NK_GEMM_BATCH; ++k) batch.g[k] = batch.g[0];
-        batch.count = count;
-        // K-slice length: the launch's stages spread over one workgroup per CU (at least a few
-        // stages each, so the load pipeline fills), every product rounded up to whole slices
-        const int limit = gemm_wg_limit();
-        int64_t total = 0;
-        for (int k = 0; k < count; ++k) total += batch.g[k].n_stages;
-        int64_t spw = (total + limit - 1) / limit;
-        if (spw < NK_GEMM_MIN_STAGES) spw = NK_GEMM_MIN_STAGES;
-        unsigned nwg = 0;
-        for (;; ++spw) {
-            nwg = 0;
-            for (int k = 0; k < count; ++k) nwg += (unsigned)((batch.g[k].n_stages + spw - 1) / spw);
-            if ((int)nwg <= limit || count >= limit) break;
+    if (q.n < 1 || q.n > NK_GEMM_MAX_PRODUCTS) NK_FAIL(NK_ERR_ARG, "dW GEMM: %d products queued", q.n);
+    int64_t stage_ns[NK_GEMM_MAX_PRODUCTS];
+    int64_t total = 0;
+    int lds_bytes = 0;
+    for (int k = 0; k < q.n; ++k) {
+        GemmOut& o = q.out[k];
+        int id = 0;
+        while (id < n_shapes && !(shapes[id][0] == o.mt && shapes[id][1] == o.nt)) ++id;
+        if (id == n_shapes) NK_FAIL(NK_ERR_UNSUPPORTED, "dW GEMM: no kernel for %d x %d tiles", o.mt, o.nt);
+        q.src[k].shape = id;
+        o.wn = shapes[id][3];
+        stage_ns[k] = shapes[id][4];
+        if (const char* e = getenv("NK_GEMM_COSTS")) {      // (tuning) "id:ns,id:ns,..."
+            for (const char* c = e; c && *c; ) {
+                int i = 0, ns = 0;
+                if (sscanf(c, "%d:%d", &i, &ns) == 2 && i == id) stage_ns[k] = ns;
+                c = strchr(c, ',');
+                if (c) ++c;
+            }
         }
+        total += q.src[k].n_stages * stage_ns[k];
+        const int need = NK_GEMM_RING * (o.mt + o.nt) * 2048;
+        if (need > lds_bytes) lds_bytes = need;
+    }
+    // K-slice lengths: every workgroup gets about the same time (at least a few stages, so the
+    // load pipeline fills), one workgroup per CU at most
+    const int limit = gemm_wg_limit();
+    int64_t per_wg = (total + limit - 1) / limit;
+    int64_t nwg = 0;
+    for (;;) {
         nwg = 0;
-        for (int k = 0; k < count; ++k) {
-            batch.g[k].stages_per_wg = spw;
-            batch.g[k].wg_begin = (int)nwg;
-            nwg += (unsigned)((batch.g[k].n_stages + spw - 1) / spw);
+        for (int k = 0; k < q.n; ++k) {
+            int64_t spw = per_wg / stage_ns[k];
+            if (spw < NK_GEMM_MIN_STAGES) spw = NK_GEMM_MIN_STAGES;
+            if (spw > 0x7fffffff) NK_FAIL(NK_ERR_ARG, "dW GEMM: batch too large");
+            q.src[k].stages_per_wg = (int)spw;
+            nwg += (q.src[k].n_stages + spw - 1) / spw;
         }
-        const int lds_bytes = NK_GEMM_RING * (MT + NT) * 2048;
-        const dim3 grid(nwg), block(512);
-        batch.partial = partial;
-        int WN = 0;
-        // (A tiles, B tiles) -> wave grid; every shape the supported networks produce
-#define NK_GEMM_CASE(MT_, NT_, WM_, WN_) \
-        if (MT == MT_ && NT == NT_) { \
-            static bool lds_allowed[NK_MAX_GPUS]; \
-            if (!lds_allowed[dev]) { \
-                NK_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_gemm<MT_, NT_, WM_, WN_>, \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
-                lds_allowed[dev] = true; \
-            } \
-            WN = WN_; \
-            if ((int64_t)nwg * gemm_slice_floats(MT_, NT_, WN_) * 4 > partial_bytes) \
-                NK_FAIL(NK_ERR_WORKSPACE, "dW GEMM: partial-sum scratch too small for %u slices of %d x %d tiles", nwg, MT, NT); \
-            hipLaunchKernelGGL((k_dw_gemm<MT_, NT_, WM_, WN_>), grid, block, lds_bytes, stream, batch); \
-        } else
-        // width 256: trunk, trunk 0, rgb, feature + alpha, skip (h + gamma(x)), views (feat + gamma(d))
-        NK_GEMM_CASE(8, 8, 2, 4) NK_GEMM_CASE(8, 2, 4, 2) NK_GEMM_CASE(1, 4, 1, 4) NK_GEMM_CASE(9, 8, 1, 8)
-        NK_GEMM_CASE(8, 10, 4, 2) NK_GEMM_CASE(4, 9, 2, 3)
-        // width 128: the same six
-        NK_GEMM_CASE(4, 4, 2, 4) NK_GEMM_CASE(4, 2, 4, 2) NK_GEMM_CASE(1, 2, 1, 2) NK_GEMM_CASE(5, 4, 1, 4)
-        NK_GEMM_CASE(4, 6, 2, 2) NK_GEMM_CASE(2, 5, 2, 1)
-        NK_FAIL(NK_ERR_UNSUPPORTED, "dW GEMM: no kernel for %d x %d tiles", MT, NT);
-#undef NK_GEMM_CASE
-        NK_CHECK_LAUNCH("k_dw_gemm");
-        const dim3 rgrid((unsigned)(MT * NT * 16 + (MT * 32 + 63) / 64), (unsigned)count);
-        hipLaunchKernelGGL(k_dw_reduce, rgrid, dim3(256), 0, stream, batch, MT, NT, WN);
+        if (nwg <= limit) break;
+        per_wg += per_wg / 64 + 1;
+    }
+    GemmBatch batch;
+    int64_t off = 0;
+    int wg = 0;
+    for (int k = 0; k < q.n; ++k) {
+        GemmSrc& g = q.src[k];
+        GemmOut& o = q.out[k];
+        const int slices = (int)((g.n_stages + g.stages_per_wg - 1) / g.stages_per_wg);
+        g.wg_begin = wg; g.partial_off = off;
+        o.n_slices = slices; o.partial_off = off;
+        wg += slices;
+        off += (int64_t)slices * gemm_slice_floats(o.mt, o.nt, o.wn);
+        batch.g[k] = g;
+    }
+    for (int k = q.n; k < NK_GEMM_MAX_PRODUCTS; ++k) batch.g[k] = batch.g[0];
+    batch.count = q.n;
+    batch.partial = partial;
+    if (off * 4 > partial_bytes)
+        NK_FAIL(NK_ERR_WORKSPACE, "dW GEMM: partial-sum scratch too small (%lld > %lld bytes)", (long long)(off * 4), (long long)partial_bytes);
+    static bool lds_allowed[NK_MAX_GPUS];
+    if (!lds_allowed[dev]) {        // the most any shape asks for: four stages of the skip layer's product
+        NK_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_gemm, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         NK_GEMM_RING * (8 + 10) * 2048));
+        lds_allowed[dev] = true;
+    }
+    hipLaunchKernelGGL(k_dw_gemm, dim3((unsigned)wg), dim3(512), lds_bytes, stream, batch);
+    NK_CHECK_LAUNCH("k_dw_gemm");
+    for (int first = 0; first < q.n; first += NK_REDUCE_BATCH) {
+        const int count = q.n - first < NK_REDUCE_BATCH ? q.n - first : NK_REDUCE_BATCH;
+        ReduceBatch rb;
+        unsigned rows = 0;
+        for (int k = 0; k < NK_REDUCE_BATCH; ++k) {
+            rb.g[k] = q.out[first + (k < count ? k : 0)];
+            const unsigned r = (unsigned)(rb.g[k].mt * rb.g[k].nt * 16 + (rb.g[k].mt * 32 + 63) / 64);
+            if (r > rows) rows = r;
+        }
+        rb.partial = partial;
+        hipLaunchKernelGGL(k_dw_reduce, dim3(rows, (unsigned)count), dim3(256), 0, stream, rb);
         NK_CHECK_LAUNCH("k_dw_reduce");
     }
     return NK_OK;
@@ -522,8 +595,8 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
     return NK_OK;
 }
 
-// GEMMs of one or two networks whose chains have run; products of equal shape share a launch,
-// across the networks too (what fills the chip when a training batch is small)
+// GEMMs of one or two networks whose chains have run: one launch for all of them (two networks
+// in one launch is what fills the chip when a training batch is small)
 int nk_mlp_backward_gemms(const NkBwdJob* jobs, int count, hipStream_t st) {
     if (count < 1 || count > 2) NK_FAIL(NK_ERR_ARG, "nk_mlp_backward_gemms: %d networks", count);
     GemmQueue q;
@@ -544,6 +617,20 @@ int nk_mlp_backward_gemms(const NkBwdJob* jobs, int count, hipStream_t st) {
             partial = (float*)((char*)jobs[1].dz + dz_region_bytes(p1, jobs[1].R, jobs[1].n));
             partial_bytes = gemm_partial_bytes(p1.W);
         }
+    }
+    static const int per_shape = []() { const char* e = getenv("NK_GEMM_PER_SHAPE"); return e ? atoi(e) : 0; }();
+    if (per_shape) {            // one launch per tile shape: how the cost column of NK_GEMM_SHAPES is measured
+        bool done[NK_GEMM_MAX_PRODUCTS] = {};
+        for (int first = 0; first < q.n; ++first) {
+            if (done[first]) continue;
+            GemmQueue sub;
+            for (int k = first; k < q.n; ++k)
+                if (!done[k] && q.out[k].mt == q.out[first].mt && q.out[k].nt == q.out[first].nt) {
+                    sub.src[sub.n] = q.src[k]; sub.out[sub.n] = q.out[k]; ++sub.n; done[k] = true;
+                }
+            if ((rc = flush_gemms(sub, partial, partial_bytes, st)) < 0) return rc;
+        }
+        return NK_OK;
     }
     return flush_gemms(q, partial, partial_bytes, st);
 }

@@ -228,12 +228,14 @@ def test_gradient_distance_to_the_fp32_oracle(nk, dev):
 
 def test_tuning_switches_keep_parity():
     """The kernel variants behind the environment switches (8 forward waves with the staggered
-    stage order, 4 backward waves without it) pass the same forward and gradient checks: the
+    stage order, 4 backward waves without it, the weight-gradient products launched shape by shape
+    over 250 workgroups instead of all in one launch) pass the same forward and gradient checks: the
     switches are read once per process, so the checks run in a child process."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NK_WAVES_FWD="8", NK_STAGGER_FWD="1", NK_WAVES_BWD="4", NK_STAGGER_BWD="0")
+    env = dict(os.environ, NK_WAVES_FWD="8", NK_STAGGER_FWD="1", NK_WAVES_BWD="4", NK_STAGGER_BWD="0",
+               NK_GEMM_PER_SHAPE="1", NK_GEMM_WGS="250")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
                         os.path.join(root, "tests", "test_gpu_backward.py"), os.path.join(root, "tests", "test_gpu_parity.py"),
                         "-k", "mlp_backward_matches_autograd or render_rays_gradients or mlp_forward or golden"],

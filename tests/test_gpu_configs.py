@@ -105,13 +105,16 @@ def test_forward_grid_1280x720(nk, golden_dir):
 
 
 def test_forward_grid_trains(nk):
-    """A short NDC training run on the grid scene at 1280 x 720: held-out PSNR rises."""
+    """A short NDC training run on the grid scene at 1280 x 720: held-out PSNR rises.  Density
+    noise 1.0 as forward-facing experiments of this lineage use: without it the first iterations are
+    bistable (about one trajectory in five settles on a constant image, 13.8 dB, and which one is
+    decided by the last bit of a gradient sum)."""
     from nerf_kinematics_amd import datasets
     from nerf_kinematics_amd.metrics import mse2psnr
     from nerf_kinematics_amd.trainer import Trainer, TrainOpts
     dev = torch.device("cuda:0")
     scene = datasets.forward_grid_scene(None, 3, 1280, 720, dev, holdout=8)
-    opts = TrainOpts(num_coarse=64, num_fine=64, num_random_rays=4096, lr=5e-4, radiance_field_noise_std=0.0, seed=1)
+    opts = TrainOpts(num_coarse=64, num_fine=64, num_random_rays=4096, lr=5e-4, radiance_field_noise_std=1.0, seed=1)
     tr = Trainer(nk.ARCH_RUN_NERF, nk.ARCH_RUN_NERF, opts, dev)
     smp = datasets.RaySampler(scene, 4096, seed=1)
 
