@@ -277,7 +277,7 @@ def main():
         tflops = flops / (k_ms * 1e-3) / 1e12
         bytes_per_launch = pts * ACT_BYTES_PER_POINT
         gbs = bytes_per_launch / (k_ms * 1e-3) / 1e9
-        shared = rays * 192 <= (1 << 20)                        # weight-gradient products of both networks in shared launches
+        shared = rays * 192 <= (1 << 20)                        # weight-gradient products of both networks in one shared launch
         res = {
             "metric": "ray-samples/sec (train)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,

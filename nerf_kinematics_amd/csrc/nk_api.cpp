@@ -51,7 +51,7 @@ int layout(const nk_arch* ac, const nk_arch* af, const nk_render_opts* o, int64_
         L->d_raw = take(R * (Nf > 0 ? N : Nc) * 16);
         L->dz = take(dzb);
         // Small batches: the coarse network gets a dZ region of its own, so that the weight-gradient
-        // GEMMs of both networks can run in shared launches after both chains (one network's
+        // GEMMs of both networks can run in one shared launch after both chains (one network's
         // products alone leave most of the chip idle).  Large batches reuse one region in turn.
         if (Nf > 0 && R * (int64_t)N <= NK_PAIR_GEMM_MAX_POINTS) L->dz_c = take(nk_dz_bytes(ac, R, Nc));
     }

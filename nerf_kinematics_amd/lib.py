@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libnerfkin.so")
 NK_LINEAGE_RUN_NERF = 0
 NK_LINEAGE_FLEXIBLE = 1
 
-# nk_render_rays_bwd runs the weight-gradient products of both networks in shared launches up to
+# nk_render_rays_bwd runs the weight-gradient products of both networks in one shared launch up to
 # this many fine-network points per call (NK_PAIR_GEMM_MAX_POINTS in csrc/nk_api.cpp)
 PAIR_GEMM_MAX_POINTS = 1 << 20
 

@@ -184,7 +184,7 @@ def test_training_psnr_tracks_the_fp32_oracle(nk, dev):
 
 def test_one_call_step_equals_the_stage_by_stage_step(nk, dev, teacher):
     """Trainer.step through nk_render_rays_fwd/_bwd (which, on a batch this small, runs the
-    weight-gradient products of both networks in shared launches) against the same step issued
+    weight-gradient products of both networks in one shared launch) against the same step issued
     stage by stage through the per-stage entry points (one nk_mlp_backward per network): same
     loss, same gradient up to the summation order of the K-slices."""
     from nerf_kinematics_amd import lib as nklib
