@@ -429,8 +429,9 @@ static int flush_gemms(GemmQueue& q, float* partial, int64_t partial_bytes, hipS
         q.src[k].shape = id;
         o.wn = shapes[id][3];
         stage_ns[k] = shapes[id][4];
-        if (const char* e = getenv("NK_GEMM_COSTS")) {      // (tuning) "id:ns,id:ns,..."
-            for (const char* c = e; c && *c; ) {
+        static const char* const cost_env = getenv("NK_GEMM_COSTS");      // (tuning) "id:ns,id:ns,..."
+        if (cost_env) {
+            for (const char* c = cost_env; c && *c; ) {
                 int i = 0, ns = 0;
                 if (sscanf(c, "%d:%d", &i, &ns) == 2 && i == id) stage_ns[k] = ns;
                 c = strchr(c, ',');
