@@ -167,7 +167,11 @@ extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const flo
         if (save) hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, true>), grid, block, LDS_, nk_stream(stream), a); \
         else hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, false>), grid, block, LDS_, nk_stream(stream), a); } while (0)
     if (a.plan.W == 256) {
+#ifdef NK_PROBE_STORE_LDS
+        constexpr int lds_bytes = 3 * (16 + 4 + 1) * 1024 + 16384;
+#else
         constexpr int lds_bytes = 3 * (16 + 4 + 1) * 1024;     // three ring slots
+#endif
         if (nw == 8) NK_FWD_LAUNCH(256, 128, 8, lds_bytes); else NK_FWD_LAUNCH(256, 128, 4, lds_bytes);
     } else {
         constexpr int lds_bytes = 3 * (8 + 4 + 1) * 1024;
