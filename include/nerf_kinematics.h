@@ -150,7 +150,9 @@ int nk_raw2outputs(const float* raw, const float* z, const float* ray_batch, int
                    int32_t n, const nk_render_opts* opts, int32_t noise_stream, float* rgb,
                    float* disp, float* acc, float* depth, float* weights, void* stream);
 /* sample_pdf on the interior coarse weights + sort(cat[z, z_samples]) -> z_all[R,Nc+Nf].
- * z_samples (optional) receives the unsorted new samples [R,Nf].                            */
+ * z_samples (optional) receives the unsorted new samples [R,Nf].  z_coarse must be ascending
+ * along each ray, as nk_stratified_z (and the reference's depth sampling) produces it: only the
+ * new samples are sorted, then the two lists are merged.                                     */
 int nk_sample_pdf(const float* z_coarse, const float* weights, int64_t R,
                   const nk_render_opts* opts, float* z_all, float* z_samples, void* stream);
 /* Backward of raw2outputs w.r.t. raw, given d(loss)/d(rgb_map) [R,3] (d_acc, d_depth optional,

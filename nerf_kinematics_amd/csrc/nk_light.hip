@@ -363,20 +363,33 @@ extern "C" int nk_raw2outputs_bwd(const float* raw, const float* z, const float*
 // ============================================================================================
 enum { PDF_MAX_NC = 256, PDF_MAX_N = 512 };
 
+// A wavefront works on its own ray and its own LDS rows: its LDS operations execute in issue
+// order, so between phases it needs no workgroup barrier, only a point the compiler does not
+// move memory operations across.
+NK_D void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The depths of the coarse pass are ascending already, so only the Nf new samples are sorted
+// (bitonic, NPF = Nf rounded up to a power of two, padded with +inf) and the two ascending lists
+// are merged by rank: a coarse depth goes to (its index + samples below it), a sample to (its
+// index + coarse depths not above it).  The result is the sorted multiset torch.sort returns.
 __global__ __launch_bounds__(256) void k_sample_pdf(
-    const float* __restrict__ zc, const float* __restrict__ wts, int64_t R, int Nc, int Nf, int NP, int perturb,
+    const float* __restrict__ zc, const float* __restrict__ wts, int64_t R, int Nc, int Nf, int NPF, int perturb,
     uint32_t seed, const nk_step_state* __restrict__ st, float* __restrict__ z_all, float* __restrict__ z_samples) {
     if (st) seed = st->render_seed;
     __shared__ float s_cdf[4][PDF_MAX_NC];
     __shared__ float s_bins[4][PDF_MAX_NC];
+    __shared__ float s_zc[4][PDF_MAX_NC];
     __shared__ float s_z[4][PDF_MAX_N];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t ray_raw = (int64_t)blockIdx.x * 4 + wv;
-    const bool live = ray_raw < R;
-    const int64_t ray = live ? ray_raw : R - 1;       // dead waves mirror the last ray (barriers stay uniform)
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+    if (ray >= R) return;                               // (no workgroup barrier below)
     const float* zr = zc + ray * Nc;
     const float* wr = wts + ray * Nc;
-    float* cdf = s_cdf[wv]; float* bins = s_bins[wv]; float* zs = s_z[wv];
+    float* cdf = s_cdf[wv]; float* bins = s_bins[wv]; float* zs = s_z[wv]; float* zcl = s_zc[wv];
     const int B = Nc - 1;          // bins = midpoints; interior weights = B - 1
     const int NW = B - 1;
     // midpoints, and the sum of (w + 1e-5) over the interior weights
@@ -407,9 +420,9 @@ __global__ __launch_bounds__(256) void k_sample_pdf(
         const int i = lane * CH + m;
         if (m < CH && i < NW) cdf[i + 1] = excl + inc[m];
     }
-    for (int i = lane; i < Nc; i += 64) zs[i] = zr[i];
-    for (int i = Nc + Nf + lane; i < NP; i += 64) zs[i] = __builtin_inff();
-    __syncthreads();
+    for (int i = lane; i < Nc; i += 64) zcl[i] = zr[i];
+    for (int i = Nf + lane; i < NPF; i += 64) zs[i] = __builtin_inff();
+    wave_sync();
     // inverse CDF
     for (int k = lane; k < Nf; k += 64) {
         const float u = perturb ? nk_rand_uniform(seed, NK_STREAM_PDF, (uint64_t)(ray * Nf + k)) : nk_linspace01(k, Nf);
@@ -422,14 +435,14 @@ __global__ __launch_bounds__(256) void k_sample_pdf(
         const float t = (u - cb) / denom;
         const float bb = bins[below], ba = bins[above];
         const float s = __fadd_rn(bb, __fmul_rn(t, ba - bb));
-        zs[Nc + k] = s;
-        if (z_samples && live) z_samples[ray * Nf + k] = s;
+        zs[k] = s;
+        if (z_samples) z_samples[ray * Nf + k] = s;
     }
-    __syncthreads();
-    // bitonic sort of NP values, ascending
-    for (int k = 2; k <= NP; k <<= 1) {
+    wave_sync();
+    // bitonic sort of the NPF sample slots, ascending
+    for (int k = 2; k <= NPF; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < NP; i += 64) {
+            for (int i = lane; i < NPF; i += 64) {
                 const int l = i ^ j;
                 if (l > i) {
                     const float a = zs[i], b = zs[l];
@@ -437,10 +450,23 @@ __global__ __launch_bounds__(256) void k_sample_pdf(
                     if ((a > b) == up) { zs[i] = b; zs[l] = a; }
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
     }
-    if (live) for (int i = lane; i < Nc + Nf; i += 64) z_all[ray * (Nc + Nf) + i] = zs[i];
+    // merge by rank
+    float* out = z_all + ray * (Nc + Nf);
+    for (int i = lane; i < Nc; i += 64) {
+        const float v = zcl[i];
+        int lo = 0, hi = Nf;                             // samples strictly below v
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (zs[mid] < v) lo = mid + 1; else hi = mid; }
+        out[i + lo] = v;
+    }
+    for (int k = lane; k < Nf; k += 64) {
+        const float v = zs[k];
+        int lo = 0, hi = Nc;                             // coarse depths not above v
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (zcl[mid] <= v) lo = mid + 1; else hi = mid; }
+        out[k + lo] = v;
+    }
 }
 
 extern "C" int nk_sample_pdf(const float* z_coarse, const float* weights, int64_t R, const nk_render_opts* o,
@@ -449,10 +475,10 @@ extern "C" int nk_sample_pdf(const float* z_coarse, const float* weights, int64_
     const int Nc = o->num_coarse, Nf = o->num_fine;
     if (Nc < 3 || Nc > PDF_MAX_NC || Nf < 1 || Nc + Nf > PDF_MAX_N)
         NK_FAIL(NK_ERR_UNSUPPORTED, "nk_sample_pdf: num_coarse=%d num_fine=%d outside 3..%d / sum<=%d", Nc, Nf, PDF_MAX_NC, PDF_MAX_N);
-    int NP = 2;
-    while (NP < Nc + Nf) NP <<= 1;
+    int NPF = 2;
+    while (NPF < Nf) NPF <<= 1;
     hipLaunchKernelGGL(k_sample_pdf, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, nk_stream(stream),
-                       z_coarse, weights, R, Nc, Nf, NP, (int)o->perturb, o->seed, o->state, z_all, z_samples);
+                       z_coarse, weights, R, Nc, Nf, NPF, (int)o->perturb, o->seed, o->state, z_all, z_samples);
     NK_CHECK_LAUNCH("k_sample_pdf");
     return NK_OK;
 }

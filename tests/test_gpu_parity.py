@@ -160,6 +160,29 @@ def test_sample_pdf(nk, dev, Nc, Nf, perturb):
     assert torch.all(z_all[:, 1:] >= z_all[:, :-1])      # sortedness, size independent
 
 
+def test_sample_pdf_merge_is_the_sorted_concatenation(nk, dev):
+    """Full batch size, ties included: z_all is bit for bit sort(cat[z_coarse, z_samples]) of the
+    kernel's own samples (the kernel sorts the new samples and merges by rank)."""
+    torch.manual_seed(3)
+    R, Nc, Nf = 16384 + 3, 64, 128
+    z = torch.sort(torch.rand(R, Nc) * 4 + 2, -1)[0]
+    z[5, 10:20] = z[5, 10]               # repeated coarse depths
+    w = torch.rand(R, Nc) ** 4
+    w[7] = 0.0; w[7, 30] = 1.0           # one spike: many samples in one bin
+    for perturb in (False, True):
+        opts = nk.make_opts(Nc, Nf, perturb=perturb, seed=11)
+        z_all, z_s = nk.sample_pdf(z.to(dev), w.to(dev), opts)
+        ref = torch.sort(torch.cat([z.to(dev), z_s], -1), -1)[0]
+        assert torch.equal(z_all, ref)
+    # a coarse depth equal to a sample: both survive, in order
+    z2 = z[:4].clone().to(dev)
+    opts = nk.make_opts(Nc, Nf, perturb=False, seed=1)
+    _, s2 = nk.sample_pdf(z2, w[:4].to(dev), opts)
+    z2[:, 40] = s2[:, 64].clamp(z2[:, 39], z2[:, 41])
+    z_all2, s3 = nk.sample_pdf(z2, w[:4].to(dev), opts)
+    assert torch.equal(z_all2, torch.sort(torch.cat([z2, s3], -1), -1)[0])
+
+
 # ---------------------------------------------------------------------------------------------
 # MLP forward (bf16 MFMA)
 # ---------------------------------------------------------------------------------------------
