@@ -150,9 +150,11 @@ int nk_raw2outputs(const float* raw, const float* z, const float* ray_batch, int
                    int32_t n, const nk_render_opts* opts, int32_t noise_stream, float* rgb,
                    float* disp, float* acc, float* depth, float* weights, void* stream);
 /* sample_pdf on the interior coarse weights + sort(cat[z, z_samples]) -> z_all[R,Nc+Nf].
- * z_samples (optional) receives the unsorted new samples [R,Nf].  z_coarse must be ascending
- * along each ray, as nk_stratified_z (and the reference's depth sampling) produces it: only the
- * new samples are sorted, then the two lists are merged.                                     */
+ * z_samples (optional) receives the unsorted new samples [R,Nf].  With z_coarse ascending along
+ * the ray, as nk_stratified_z (and the reference's depth sampling) produces it, only the new
+ * samples are sorted and the two lists are merged; a ray whose coarse depths are not ascending
+ * (or hold a NaN) is detected and sorted whole, like the reference's torch.sort of the
+ * concatenation (NaNs then end up in unspecified slots).                                      */
 int nk_sample_pdf(const float* z_coarse, const float* weights, int64_t R,
                   const nk_render_opts* opts, float* z_all, float* z_samples, void* stream);
 /* Backward of raw2outputs w.r.t. raw, given d(loss)/d(rgb_map) [R,3] (d_acc, d_depth optional,
@@ -232,7 +234,10 @@ int nk_set_stage_events(void** events, int count);
  * image, one copy per GPU, held until the process ends.  The device the stream belongs to must be
  * current.  Fails with NK_ERR_WORKSPACE when R rays at opts' sample counts need more than that
  * (about 5.4 KB per ray at 64 + 128 samples: 12 000 rays); allocates and frees nothing.  All calls
- * on one GPU share the array: calls that overlap on one GPU (two streams, two threads) race.    */
+ * on one GPU share the array: calls that overlap on one GPU (two streams, two threads) race.
+ * The first call on a device looks the array's address up (hipGetSymbolAddress, which may load the
+ * code object): make one call on each device OUTSIDE stream capture before capturing calls into a
+ * HIP graph; later calls only launch kernels.                                                   */
 #define NK_NOALLOC_SCRATCH_BYTES (64u << 20)
 int nk_render_rays_fwd_noalloc(const nk_arch* arch_coarse, const void* packed_coarse,
                                const nk_arch* arch_fine, const void* packed_fine,

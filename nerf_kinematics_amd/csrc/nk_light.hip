@@ -64,13 +64,14 @@ __global__ void k_sample_training_rays(CamArgs a, const uint8_t* __restrict__ im
     if (pixel_idx) pixel_idx[r] = (int32_t)pix;
 }
 
-__global__ void k_sample_training_rays_dev(const nk_camera* __restrict__ cams, const uint8_t* __restrict__ images,
+__global__ void k_sample_training_rays_dev(const nk_camera* __restrict__ cams, int n_views, const uint8_t* __restrict__ images,
                                            int64_t image_stride, int channels, int white,
                                            const nk_step_state* __restrict__ st, int64_t R, float* __restrict__ rb,
                                            float* __restrict__ target, int32_t* __restrict__ pixel_idx) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const int view = st->view;
+    if (view < 0 || view >= n_views) return;        // a step state that was never set: draw nothing rather than read outside the tables
     const nk_camera cam = cams[view];
     const uint64_t npix = (uint64_t)cam.H * (uint64_t)cam.W;
     const int64_t pix = (int64_t)(((uint64_t)nk_rand_u32(st->pixel_seed, NK_STREAM_PIXELS, st->pixel_counter + (uint64_t)r) * npix) >> 32);
@@ -94,7 +95,7 @@ extern "C" int nk_sample_training_rays_dev(const nk_camera* cams, int32_t n_view
     if (channels != 3 && channels != 4)
         NK_FAIL(NK_ERR_ARG, "nk_sample_training_rays_dev: %d channels (3 or 4)", channels);
     hipLaunchKernelGGL(k_sample_training_rays_dev, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, nk_stream(stream),
-                       cams, images, image_stride, channels, white_background, state, R, ray_batch, target, pixel_idx);
+                       cams, (int)n_views, images, image_stride, channels, white_background, state, R, ray_batch, target, pixel_idx);
     NK_CHECK_LAUNCH("k_sample_training_rays_dev");
     return NK_OK;
 }
@@ -372,12 +373,29 @@ NK_D void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ascending bitonic sort of the first n (a power of two) floats of one wavefront's LDS row
+NK_D void wave_bitonic(float* v, int n, int lane) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < n; i += 64) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float a = v[i], b = v[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { v[i] = b; v[l] = a; }
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
 // The depths of the coarse pass are ascending already, so only the Nf new samples are sorted
 // (bitonic, NPF = Nf rounded up to a power of two, padded with +inf) and the two ascending lists
 // are merged by rank: a coarse depth goes to (its index + samples below it), a sample to (its
 // index + coarse depths not above it).  The result is the sorted multiset torch.sort returns.
 __global__ __launch_bounds__(256) void k_sample_pdf(
-    const float* __restrict__ zc, const float* __restrict__ wts, int64_t R, int Nc, int Nf, int NPF, int perturb,
+    const float* __restrict__ zc, const float* __restrict__ wts, int64_t R, int Nc, int Nf, int NPF, int NPA, int perturb,
     uint32_t seed, const nk_step_state* __restrict__ st, float* __restrict__ z_all, float* __restrict__ z_samples) {
     if (st) seed = st->render_seed;
     __shared__ float s_cdf[4][PDF_MAX_NC];
@@ -439,22 +457,24 @@ __global__ __launch_bounds__(256) void k_sample_pdf(
         if (z_samples) z_samples[ray * Nf + k] = s;
     }
     wave_sync();
-    // bitonic sort of the NPF sample slots, ascending
-    for (int k = 2; k <= NPF; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < NPF; i += 64) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const float a = zs[i], b = zs[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { zs[i] = b; zs[l] = a; }
-                }
-            }
-            wave_sync();
-        }
-    }
-    // merge by rank
+    // The merge by rank needs ascending coarse depths (what nk_stratified_z and the reference's depth
+    // sampling produce).  Any other input -- unsorted, or holding a NaN (every comparison with it is
+    // false) -- takes the reference's own route: sort the concatenation of both lists.
+    bool asc = true;
+    for (int i = lane; i + 1 < Nc; i += 64) asc = asc && (zcl[i] <= zcl[i + 1]);
+    const bool merge = __builtin_amdgcn_ballot_w64(!asc) == 0;      // wave-uniform
     float* out = z_all + ray * (Nc + Nf);
+    if (!merge) {
+        for (int i = lane; i < Nc; i += 64) zs[Nf + i] = zcl[i];
+        for (int i = Nc + Nf + lane; i < NPA; i += 64) zs[i] = __builtin_inff();
+        wave_sync();
+        wave_bitonic(zs, NPA, lane);
+        for (int i = lane; i < Nc + Nf; i += 64) out[i] = zs[i];
+        return;
+    }
+    // bitonic sort of the NPF sample slots, ascending
+    wave_bitonic(zs, NPF, lane);
+    // merge by rank
     for (int i = lane; i < Nc; i += 64) {
         const float v = zcl[i];
         int lo = 0, hi = Nf;                             // samples strictly below v
@@ -475,10 +495,11 @@ extern "C" int nk_sample_pdf(const float* z_coarse, const float* weights, int64_
     const int Nc = o->num_coarse, Nf = o->num_fine;
     if (Nc < 3 || Nc > PDF_MAX_NC || Nf < 1 || Nc + Nf > PDF_MAX_N)
         NK_FAIL(NK_ERR_UNSUPPORTED, "nk_sample_pdf: num_coarse=%d num_fine=%d outside 3..%d / sum<=%d", Nc, Nf, PDF_MAX_NC, PDF_MAX_N);
-    int NPF = 2;
+    int NPF = 2, NPA = 2;             // sample count and sample + coarse count, rounded up to powers of two
     while (NPF < Nf) NPF <<= 1;
+    while (NPA < Nc + Nf) NPA <<= 1;
     hipLaunchKernelGGL(k_sample_pdf, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, nk_stream(stream),
-                       z_coarse, weights, R, Nc, Nf, NPF, (int)o->perturb, o->seed, o->state, z_all, z_samples);
+                       z_coarse, weights, R, Nc, Nf, NPF, NPA, (int)o->perturb, o->seed, o->state, z_all, z_samples);
     NK_CHECK_LAUNCH("k_sample_pdf");
     return NK_OK;
 }

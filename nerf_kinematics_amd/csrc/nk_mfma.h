@@ -137,22 +137,14 @@ struct WStream {
     // the true count only waits longer; a larger one would race.
     template <int N>
     NK_D void flip_keep() {
-#ifdef NK_PROBE_NO_BARRIER     // (timing probe, wrong results: stages are not synchronised across the workgroup)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-#else
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-#endif
         advance();
     }
     // Same, naming the tile's accumulator: its MFMAs are register-only instructions that hipcc
     // otherwise sinks below the barrier, stretching the live range of 16 weight fragments.
     template <int N>
     NK_D void flip_keep(f32x16& acc) {
-#ifdef NK_PROBE_NO_BARRIER
-        asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)" : "+v"(acc) : "n"(N) : "memory");
-#else
         asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)\n\ts_barrier" : "+v"(acc) : "n"(N) : "memory");
-#endif
         advance();
     }
     NK_D const char* stage() const { return ring + cur * slot_bytes; }
@@ -195,11 +187,7 @@ NK_D f32x16 tile_run(f32x16 acc, const char* stage, int lane, const Frag* b0, co
         if constexpr (!__is_same(WS, void)) {       // one piece of the announced stream load every third k-step
             if (NK_DMA_SPREAD && ks % 3 == 1 && ks / 3 < 6) ws->piece(ks / 3);
         }
-#ifdef NK_PROBE_HALF_LDS      // (timing probe, wrong results: every other weight fragment is not read)
-        if (ks + LA < NK && (ks & 1)) {
-#else
         if (ks + LA < NK) {
-#endif
             a[ks % LA] = *(const bf16x8*)(base + (ks + LA) * 1024);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
@@ -300,10 +288,6 @@ NK_D uint32_t relu_pk_bf16(uint32_t p) {
 }
 
 NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1) {
-#ifdef NK_PROBE_NO_CONVERT      // (timing probe, wrong results: accumulator bits passed on unconverted)
-    for (int w = 0; w < 4; ++w) { f0.u[w] = (uint32_t)__float_as_int(a[w]); f1.u[w] = (uint32_t)__float_as_int(a[8 + w]); }
-    return;
-#endif
 #if NK_RELU_PACKED
     // all eight converts first, then the eight packed maxima: no instruction waits on its neighbour
 #pragma unroll

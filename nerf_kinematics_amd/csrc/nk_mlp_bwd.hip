@@ -111,7 +111,8 @@ NK_D void gemm_wait_barrier() {
 
 // ONE launch runs every weight-gradient product of a network (of both networks when the batch
 // is small), whatever their shapes: the launch is one round of workgroups over the chip, the
-// points of each product are cut into K-slices of about equal BYTES, one per workgroup (product k
+// points of each product are cut into K-slices of about equal predicted TIME (the ns-per-stage
+// column of NK_GEMM_SHAPES), one per workgroup (product k
 // owns workgroups [wg_begin_k, wg_begin_{k+1})), and a workgroup branches once into the body
 // compiled for its product's tile shape.  A workgroup does not add its K-slice into the gradient
 // (device-scope fp32 atomics on one 256-KiB matrix run at ~0.6 TB/s chip-wide): it stores its

@@ -163,25 +163,11 @@ extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const flo
     a.stagger = env_stagger;
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
     const bool save = act_save != nullptr;
-#ifdef NK_PROBE_LDS_PAD
-#define NK_FWD_ALLOW(W_, WD_, NW_, LDS_) \
-        (void)hipFuncSetAttribute((const void*)k_mlp_fwd<W_, WD_, NW_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_); \
-        (void)hipFuncSetAttribute((const void*)k_mlp_fwd<W_, WD_, NW_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_);
-#else
-#define NK_FWD_ALLOW(W_, WD_, NW_, LDS_)
-#endif
 #define NK_FWD_LAUNCH(W_, WD_, NW_, LDS_) do { \
-        NK_FWD_ALLOW(W_, WD_, NW_, LDS_) \
         if (save) hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, true>), grid, block, LDS_, nk_stream(stream), a); \
         else hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, false>), grid, block, LDS_, nk_stream(stream), a); } while (0)
     if (a.plan.W == 256) {
-#if defined(NK_PROBE_LDS_PAD)      // (timing probe: a padded workgroup leaves room for one per CU only)
-        constexpr int lds_bytes = 3 * (16 + 4 + 1) * 1024 + NK_PROBE_LDS_PAD;
-#elif defined(NK_PROBE_STORE_LDS)
-        constexpr int lds_bytes = 3 * (16 + 4 + 1) * 1024 + 16384;
-#else
         constexpr int lds_bytes = 3 * (16 + 4 + 1) * 1024;     // three ring slots
-#endif
         if (nw == 8) NK_FWD_LAUNCH(256, 128, 8, lds_bytes); else NK_FWD_LAUNCH(256, 128, 4, lds_bytes);
     } else {
         constexpr int lds_bytes = 3 * (8 + 4 + 1) * 1024;

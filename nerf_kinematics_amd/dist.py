@@ -70,11 +70,14 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
-def allreduce_sum_start(flat: torch.Tensor, group=None):
+def allreduce_sum_start(flat: torch.Tensor, group=None, force: bool = False):
     """Start summing `flat` over ranks in place and return a handle for allreduce_wait (None when
     the sum is already complete).  RCCL: the collective runs on its own stream behind everything
-    queued on the current stream so far, so kernels launched afterwards overlap it."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    queued on the current stream so far, so kernels launched afterwards overlap it.  ``force``
+    issues the collective on a one-rank group too (tests of the stream ordering)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_world_size(group) == 1 and not force:
         return None
     if flat.is_cuda and dist.get_backend(group) == "gloo":
         allreduce_sum_(flat, group)         # host copy, synchronous (tests with several ranks on one GPU)

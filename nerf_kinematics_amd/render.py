@@ -146,7 +146,11 @@ def raw2outputs_backward(raw, z, ray_batch, opts, noise_stream, d_rgb, d_acc=Non
 
 def sample_pdf(z_coarse: torch.Tensor, weights: torch.Tensor, opts: _lib.NkRenderOpts
                ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Hierarchical samples from the interior coarse weights; returns (sorted z_all, new samples)."""
+    """Hierarchical samples from the interior coarse weights; returns (sorted z_all, new samples).
+
+    Fast path: ``z_coarse`` ascending along each ray (what ``stratified_z`` produces) -- only the new
+    samples are sorted and the two lists merged.  Rays whose coarse depths are not ascending are
+    sorted whole, as ``torch.sort(cat[z, z_samples])`` would."""
     L = _lib.load()
     z = _f32(z_coarse, "z_coarse", (None, opts.num_coarse))
     w = _f32(weights, "weights", (z.shape[0], opts.num_coarse))

@@ -430,11 +430,12 @@ def _run_net(net: NeRFNet, ray_batch: torch.Tensor, z: torch.Tensor) -> torch.Te
 
 
 def render_rays(ray_batch: torch.Tensor, coarse: NeRFNet, fine: Optional[NeRFNet], opts: RenderOpts,
-                ) -> Dict[str, torch.Tensor]:
+                ray_offset: int = 0) -> Dict[str, torch.Tensor]:
     """Volume-render a batch of rays.  ray_batch [R,11] -> dict with fine and coarse maps.
 
     Random draws (only when ``perturb`` / noise are on) come from the shared hash streams,
-    indexed ``ray*n + sample``.
+    indexed ``ray*n + sample``.  ``ray_offset``: index of the first row inside a larger batch, so
+    that a large batch can be evaluated piece by piece with the draws of the whole batch.
     """
     R = ray_batch.shape[0]
     dt = ray_batch.dtype
@@ -442,14 +443,14 @@ def render_rays(ray_batch: torch.Tensor, coarse: NeRFNet, fine: Optional[NeRFNet
     rays_d = ray_batch[:, 3:6]
     u_strat = None
     if opts.perturb:
-        idx = np.arange(R * Nc, dtype=np.uint64)
+        idx = np.arange(R * Nc, dtype=np.uint64) + np.uint64(ray_offset * Nc)
         u_strat = torch.from_numpy(rand_uniform(opts.seed, STREAM_STRATIFIED, idx)).to(dt).view(R, Nc)
     z = stratified_z(ray_batch, Nc, opts.lindisp, u_strat)
 
     def noise_for(stream, n):
         if opts.radiance_field_noise_std <= 0.0:
             return None
-        idx = np.arange(R * n, dtype=np.uint64)
+        idx = np.arange(R * n, dtype=np.uint64) + np.uint64(ray_offset * n)
         return torch.from_numpy(rand_normal(opts.seed, stream, idx)).to(dt).view(R, n) * opts.radiance_field_noise_std
 
     raw_c = _run_net(coarse, ray_batch, z)
@@ -461,7 +462,7 @@ def render_rays(ray_batch: torch.Tensor, coarse: NeRFNet, fine: Optional[NeRFNet
         mids = 0.5 * (z[..., 1:] + z[..., :-1])
         u_pdf = None
         if opts.perturb:
-            idx = np.arange(R * Nf, dtype=np.uint64)
+            idx = np.arange(R * Nf, dtype=np.uint64) + np.uint64(ray_offset * Nf)
             u_pdf = torch.from_numpy(rand_uniform(opts.seed, STREAM_PDF, idx)).to(dt).view(R, Nf)
         z_f = sample_pdf(mids, w_c[..., 1:-1].detach(), Nf, det=not opts.perturb, u=u_pdf).detach()
         z_all, _ = torch.sort(torch.cat([z, z_f], -1), -1)

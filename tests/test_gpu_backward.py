@@ -128,6 +128,130 @@ def test_render_rays_gradients(nk, dev, which):
     check_grads(arch_f, f.flat.grad, ffo.grad, tol=5e-2)
 
 
+# ---------------------------------------------------------------------------------------------
+# gradients in the launch regime the benchmark runs: more than 2^20 fine points per call, where
+# nk_render_rays_bwd launches the weight-gradient products network by network (about 256 K-slices
+# of hundreds of 32-point stages each, summed by k_dw_reduce) instead of in one shared launch
+# ---------------------------------------------------------------------------------------------
+def oracle_pair_grads(arch_c, arch_f, fc, ff, rb, target, kw, chunk):
+    """Gradient of the NeRF loss through the bf16-emulating oracle, evaluated in pieces of `chunk`
+    rays (the loss is a mean over rays, the random draws are indexed by the ray's row in the whole
+    batch), so that a batch of a million points fits the host."""
+    fco, ffo = fc.clone().requires_grad_(True), ff.clone().requires_grad_(True)
+    R, total = rb.shape[0], 0.0
+    for s in range(0, R, chunk):
+        co = O.NeRFNet.from_flat(oarch(arch_c), fco, emulate_bf16=True)
+        fo = O.NeRFNet.from_flat(oarch(arch_f), ffo, emulate_bf16=True)
+        out = O.render_rays(rb[s:s + chunk], co, fo, O.RenderOpts(64, 128, **kw), ray_offset=s)
+        t = target[s:s + chunk]
+        part = (((out["rgb_coarse"] - t) ** 2).sum() + ((out["rgb_fine"] - t) ** 2).sum()) / (3 * R)
+        part.backward()
+        total += float(part.detach())
+    return total, fco.grad, ffo.grad
+
+
+def report_grads(tag, arch, got, ref):
+    rel = float((got.cpu() - ref).norm() / ref.norm())
+    worst = max(per_tensor_rel_err(arch, got.cpu(), ref).items(), key=lambda kv: kv[1][0] if kv[1][1] > 1e-6 * float(ref.norm()) else 0)
+    print(f"{tag}: whole-gradient relative L2 {rel:.4f}; worst tensor {worst[0]} {worst[1][0]:.4f}")
+
+
+@pytest.fixture(scope="module")
+def headline_batch(nk, dev):
+    """8x256 pair after 300 training iterations (so rays meet density), one batch of 5 507 rays at
+    64 + 128 samples = 1 057 344 fine points: above the shared-launch limit, and ragged -- neither
+    point count is a multiple of the 256-point workgroup or of a K-slice, so the last workgroup of
+    each chain and the last K-slice of every product are short."""
+    from nerf_kinematics_amd.datasets import RaySampler, teacher_scene
+    from nerf_kinematics_amd.trainer import Trainer, TrainOpts
+    from nerf_kinematics_amd import lib as nklib
+    arch = nk.ARCH_RUN_NERF
+    R = 5507
+    assert R * 192 > nklib.PAIR_GEMM_MAX_POINTS
+    scene = teacher_scene(None, 8, 0, 100, dev)
+    opts = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=1024, perturb=True, radiance_field_noise_std=0.2,
+                     lr=5e-4, seed=42)
+    tr = Trainer(arch, arch, opts, dev)
+    smp = RaySampler(scene, 1024, seed=3)
+    for i in range(300):
+        tr.step(*smp.next(i))
+    rb, target = RaySampler(scene, R, seed=8).next(300)
+    rb, target = rb.clone(), target.clone()
+    fc, ff = tr.coarse.flat.detach().clone(), tr.fine.flat.detach().clone()
+    seed = (42 + 0x9E3779B1) & 0xFFFFFFFF        # the seed Trainer.step uses in its first iteration
+    kw = dict(perturb=True, radiance_field_noise_std=0.2, seed=seed)
+    loss_ref, gc_ref, gf_ref = oracle_pair_grads(arch, arch, fc.cpu(), ff.cpu(), rb.cpu(), target.cpu(), kw, chunk=1024)
+    return dict(arch=arch, R=R, rb=rb, target=target, fc=fc, ff=ff, kw=kw, loss=loss_ref, gc=gc_ref, gf=gf_ref)
+
+
+def test_large_batch_gradients_8x256(nk, dev, headline_batch):
+    """(a) one nk_render_rays_fwd / _bwd call on the headline shape above 2^20 fine points."""
+    b = headline_batch
+    arch = b["arch"]
+    c, f = nk.NeRFModel(arch, b["fc"].clone()), nk.NeRFModel(arch, b["ff"].clone())
+    c.flat.requires_grad_(True); f.flat.requires_grad_(True)
+    out = nk.render_rays(b["rb"], c, f, num_coarse=64, num_fine=128, **b["kw"])
+    loss = ((out[3] - b["target"]) ** 2).mean() + ((out[0] - b["target"]) ** 2).mean()
+    loss.backward()
+    print(f"loss: HIP {float(loss.detach()):.6f}, oracle {b['loss']:.6f}")
+    assert abs(float(loss.detach()) - b["loss"]) < 2e-3 * b["loss"] + 1e-5
+    report_grads("8x256 coarse, 5507 rays", arch, c.flat.grad, b["gc"])
+    report_grads("8x256 fine,   5507 rays", arch, f.flat.grad, b["gf"])
+    check_grads(arch, c.flat.grad, b["gc"], tol=5e-2)
+    check_grads(arch, f.flat.grad, b["gf"], tol=5e-2)
+
+
+def test_large_batch_gradients_split_backward(nk, dev, headline_batch):
+    """(c) the same batch through Trainer.step with the data-parallel step's two backward calls
+    (fine network, then coarse: the path that overlaps an all-reduce per network)."""
+    from nerf_kinematics_amd.trainer import Trainer, TrainOpts
+    b = headline_batch
+    arch = b["arch"]
+    opts = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=b["R"], perturb=True, radiance_field_noise_std=0.2,
+                     lr=5e-4, seed=42)
+    tr = Trainer(arch, arch, opts, dev)
+    tr.overlap_allreduce = True
+    nc, ncp = tr._nc, tr._nc_pad
+    tr.params[:nc] = b["fc"]; tr.params[ncp:] = b["ff"]
+    tr.coarse.pack(); tr.fine.pack()
+    loss = float(tr.step(b["rb"], b["target"]))
+    assert tr.ropts.seed == b["kw"]["seed"]
+    assert abs(loss - b["loss"]) < 2e-3 * b["loss"] + 1e-5
+    gc, gf = tr.grad_views()
+    report_grads("8x256 coarse, split backward", arch, gc, b["gc"])
+    report_grads("8x256 fine,   split backward", arch, gf, b["gf"])
+    check_grads(arch, gc, b["gc"], tol=5e-2)
+    check_grads(arch, gf, b["gf"], tol=5e-2)
+
+
+def test_large_batch_gradients_4x128(nk, dev):
+    """(b) the reference's own network shape with its trained lego weights at 16 384 rays x (64 + 128)
+    samples = 3.1 M fine points, the ray count bench.py runs."""
+    import numpy as np
+    from nerf_kinematics_amd.datasets import RaySampler, teacher_scene
+    arch = nk.ARCH_LEGO_CKPT
+    w = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lego_lowres3_weights.npz"))
+    fc, ff = torch.from_numpy(w["coarse"]).clone(), torch.from_numpy(w["fine"]).clone()
+    R = 16384
+    scene = teacher_scene(None, 4, 0, 100, dev)
+    rb, target = RaySampler(scene, R, seed=5).next(0)
+    # a target the trained networks do not already fit, so the gradient is not noise around zero
+    target = (target * 0.5 + 0.25 * torch.rand(R, 3, generator=torch.Generator().manual_seed(1)).to(dev)).contiguous()
+    kw = dict(perturb=True, radiance_field_noise_std=0.2, seed=11)
+    c, f = nk.NeRFModel(arch, fc.to(dev)), nk.NeRFModel(arch, ff.to(dev))
+    c.flat.requires_grad_(True); f.flat.requires_grad_(True)
+    out = nk.render_rays(rb, c, f, num_coarse=64, num_fine=128, **kw)
+    loss = ((out[3] - target) ** 2).mean() + ((out[0] - target) ** 2).mean()
+    loss.backward()
+    loss_ref, gc_ref, gf_ref = oracle_pair_grads(arch, arch, fc, ff, rb.cpu(), target.cpu(), kw, chunk=2048)
+    print(f"loss: HIP {float(loss.detach()):.6f}, oracle {loss_ref:.6f}")
+    assert abs(float(loss.detach()) - loss_ref) < 2e-3 * loss_ref + 1e-5
+    report_grads("4x128 coarse, 16384 rays", arch, c.flat.grad, gc_ref)
+    report_grads("4x128 fine,   16384 rays", arch, f.flat.grad, gf_ref)
+    check_grads(arch, c.flat.grad, gc_ref, tol=5e-2)
+    check_grads(arch, f.flat.grad, gf_ref, tol=5e-2)
+
+
 def test_mse_loss_kernel(nk, dev):
     torch.manual_seed(0)
     R = 1000

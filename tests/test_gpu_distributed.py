@@ -120,6 +120,63 @@ def test_two_rank_trainer_step_equals_single_process():
     assert float(d.mean()) < 1e-5 and float(d.max()) <= 2 * 5e-3 + 1e-6
 
 
+def _rccl_one_rank_worker(port, q):
+    """A one-rank RCCL group drives the asynchronous branch of the split data-parallel step: the
+    collective of each half of the flat gradient runs on RCCL's own stream, ordered against the
+    second backward call, the next step's fill of the gradient buffer and the Adam kernel."""
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import nerf_kinematics_amd as nk
+    from nerf_kinematics_amd import datasets
+    from nerf_kinematics_amd.trainer import Trainer, TrainOpts
+    rays = 5600                                     # x 192 samples: above the shared-launch limit
+    opts = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=rays, perturb=True, radiance_field_noise_std=0.2,
+                     lr=5e-3, seed=42)
+    scene = datasets.teacher_scene(None, 4, 0, 100, dev)
+    smp = datasets.RaySampler(scene, rays, seed=6)
+    a = Trainer(nk.ARCH_LEGO_CKPT, nk.ARCH_LEGO_CKPT, opts, dev)
+    b = Trainer(nk.ARCH_LEGO_CKPT, nk.ARCH_LEGO_CKPT, opts, dev)
+    b.overlap_allreduce = True
+    b.force_collective = True
+    same, issued = True, 0
+    real = torch.distributed.all_reduce
+
+    def counting(*args, **kw):
+        nonlocal issued
+        issued += 1 if kw.get("async_op") else 0
+        return real(*args, **kw)
+    torch.distributed.all_reduce = counting
+    for i in range(6):
+        rb, tgt = smp.next(i)
+        la, lb = float(a.step(rb, tgt)), float(b.step(rb, tgt))
+        same = same and torch.equal(a.grad, b.grad) and torch.equal(a.params, b.params) and abs(la - lb) <= 1e-6 * abs(la)
+    torch.distributed.all_reduce = real
+    q.put((same, issued, float(a.grad.abs().sum())))
+    faulthandler.cancel_dump_traceback_later()
+    torch.distributed.destroy_process_group()
+
+
+def test_async_allreduce_branch_on_a_one_rank_rccl_group():
+    """Bit-identical gradient and parameters, six steps in a row, between the plain step and the
+    split step whose two all-reduces really are issued (asynchronously, on RCCL) -- RCCL itself,
+    with more than one rank, needs more than one GPU and is not covered here."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU and the HIP library; there is no CPU fallback")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    same, issued, gnorm = q.get(timeout=170)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert issued == 12, issued             # two asynchronous collectives per step
+    assert gnorm > 0 and same
+
+
 def test_bench_two_ranks_share_one_gpu():
     """`python bench.py --gpus 2` with no launcher: two ranks (gloo, both on this GPU) run the real
     training step; the one JSON line reports both ranks' rays."""

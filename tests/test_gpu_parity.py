@@ -183,6 +183,30 @@ def test_sample_pdf_merge_is_the_sorted_concatenation(nk, dev):
     assert torch.equal(z_all2, torch.sort(torch.cat([z2, s3], -1), -1)[0])
 
 
+def test_sample_pdf_with_unsorted_coarse_depths(nk, dev):
+    """The reference sorts the concatenation whatever the order of the coarse depths.  Rays whose
+    coarse depths are not ascending leave the merge-by-rank path and are sorted whole: every slot
+    of z_all is written (the buffer starts as NaN) and equals torch.sort of the concatenation,
+    ascending rays in the same call included."""
+    torch.manual_seed(4)
+    for Nc, Nf in ((64, 128), (16, 40), (200, 300)):
+        R = 37
+        z = torch.sort(torch.rand(R, Nc) * 4 + 2, -1)[0]
+        z[3] = z[3].flip(0)                          # descending
+        z[8, [5, 9]] = z[8, [9, 5]]                  # one swapped pair
+        z[20] = z[20][torch.randperm(Nc)]            # shuffled
+        w = torch.rand(R, Nc) ** 2
+        opts = nk.make_opts(Nc, Nf, perturb=True, seed=3)
+        zd = z.to(dev)
+        z_all = torch.full((R, Nc + Nf), float("nan"), device=dev)
+        z_s = torch.empty(R, Nf, device=dev)
+        from nerf_kinematics_amd import lib as nklib
+        nklib.check(nk.load().nk_sample_pdf(zd.data_ptr(), w.to(dev).data_ptr(), R, opts, z_all.data_ptr(), z_s.data_ptr(),
+                                            torch.cuda.current_stream(dev).cuda_stream))
+        assert not torch.isnan(z_all).any()
+        assert torch.equal(z_all, torch.sort(torch.cat([zd, z_s], -1), -1)[0])
+
+
 # ---------------------------------------------------------------------------------------------
 # MLP forward (bf16 MFMA)
 # ---------------------------------------------------------------------------------------------

@@ -450,3 +450,27 @@ def test_graph_step_equals_eager_step(nk, dev, teacher):
     out = runs[0][0].render(rb[:64].contiguous())
     out_ref = ref.render(rb[:64].contiguous())
     assert torch.equal(out["rgb_fine"], out_ref["rgb_fine"])
+
+
+def test_device_state_sampler_ignores_a_view_outside_the_tables(nk, dev, teacher):
+    """nk_sample_training_rays_dev reads the view index from device memory when it runs; an index
+    outside the camera table / image stack (a step state that was never set) must not be followed."""
+    import ctypes as C
+    from nerf_kinematics_amd import lib as nklib
+    from nerf_kinematics_amd.datasets import RaySampler
+    from nerf_kinematics_amd.trainer import GraphedStep
+    tr = _trainer(nk, dev, rays=256, seed=2)
+    gs = GraphedStep(tr, RaySampler(teacher, 256, seed=3), capture=False)
+    L = nk.load()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rb = torch.full((256, 11), float("nan"), device=dev)
+    tgt = torch.full((256, 3), float("nan"), device=dev)
+    for view, drawn in ((gs.n_views, False), (-1, False), (2 ** 30, False), (gs.n_views - 1, True)):
+        state = nklib.NkStepState(render_seed=1, pixel_seed=2, pixel_counter=0, view=view)
+        sd = torch.zeros(C.sizeof(nklib.NkStepState), dtype=torch.uint8, device=dev)
+        nklib.check(L.nk_set_step_state(state, sd.data_ptr(), st))
+        nklib.check(L.nk_sample_training_rays_dev(gs.cams.data_ptr(), gs.n_views, teacher.images.data_ptr(), gs.image_stride,
+                                                  gs.channels, gs.white, sd.data_ptr(), 256, rb.data_ptr(), tgt.data_ptr(),
+                                                  None, st))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(rb).all()) == drawn and bool(torch.isfinite(tgt).all()) == drawn

@@ -146,3 +146,22 @@ def test_adam_matches_torch():
         opt.step()
         O.adam_step(q, g * step, m, v, step, 5e-3)
     assert torch.allclose(q, ref.detach(), atol=1e-6)
+
+
+def test_render_rays_in_pieces_equals_whole_batch():
+    """ray_offset: a batch evaluated piece by piece draws the jitter / noise of the whole batch."""
+    torch.manual_seed(0)
+    arch = O.ARCH_LEGO_CKPT
+    co = O.NeRFNet.from_flat(arch, O.NeRFNet.init_flat(arch, 1))
+    fo = O.NeRFNet.from_flat(arch, O.NeRFNet.init_flat(arch, 2))
+    focal = 0.5 * 8 / math.tan(0.5 * 0.6911112070083618)
+    ro, rd = O.get_rays(8, 8, focal, O.spherical_pose(45.0, -30.0, 4.0))
+    rb = O.make_ray_batch(ro, rd, 2.0, 6.0)[:20]
+    opts = O.RenderOpts(16, 24, perturb=True, radiance_field_noise_std=0.3, seed=9)
+    with torch.no_grad():
+        whole = O.render_rays(rb, co, fo, opts)
+        parts = [O.render_rays(rb[s:s + 7], co, fo, opts, ray_offset=s) for s in range(0, 20, 7)]
+    for k in ("rgb_fine", "rgb_coarse", "z_all", "weights_fine"):
+        got = torch.cat([p[k] for p in parts])
+        assert torch.allclose(got, whole[k], rtol=1e-5, atol=1e-6), k
+    assert torch.equal(torch.cat([p["z_coarse"] for p in parts]), whole["z_coarse"])
