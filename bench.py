@@ -19,16 +19,19 @@ inputs resident in HBM.  --scaling weak (default): every GPU takes --rays rays p
 --scaling strong: --rays is the global batch, split evenly over the GPUs.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel, the fused Embedder + MLP forward that saves activations
-                (k_mlp_fwd<256,128,4,true>, two launches per step), priced against the bf16 MFMA
-                peak: FLOP per launch / mean launch duration, from HIP events the library records
-                around those launches inside the timed steps (nk_set_stage_events); the HBM view of
-                the same launches (bytes written / duration) sits beside it under "hbm"
-  kernels       mean duration of the other heavy launches of the timed steps, same events
+  roofline      the time-dominant kernel of the step, k_dw_gemm (all weight-gradient products of a
+                network in one launch + its k_dw_reduce; two launches per step), priced against the
+                bf16 MFMA peak: FLOP per launch / mean launch duration, from HIP events the library
+                records at the stage boundaries inside the timed steps (nk_set_stage_events); its HBM
+                view (bytes read / duration) sits beside it under "hbm", and "per_kernel" holds the
+                same two views of the three heavy launches (forward chain, backward chain, dW)
+  value_long    the same step timed over >= 200 further steps (the driver's --steps 20 is 0.4 s)
   value_r1024   the same step at the reference's own batch size (num_random_rays: 1024), N == 1
+  render_400x400_ms  whole-image inference (nerf.validation settings), one 400x400 view, N == 1
   heldout_psnr  PSNR on held-out views after a short fixed-seed training run, N == 1
   cpu_baseline  the CPU restatement (oracle, torch CPU fp32) of the same training step, timed on
                 this host on a bounded ray sample (rank 0, N == 1 only)
+  comm          N > 1 only: all-reduce time per step, per-rank step times, RCCL version and settings
 """
 import argparse
 import json
@@ -42,12 +45,25 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_EVAL_8x256 = 1186816          # forward FLOPs of one 8x256 NeRF evaluation (2 x 593 408 MAC)
+FLOP_PER_EVAL_8x256 = 1186816          # forward FLOPs of one 8x256 NeRF evaluation (2 x 593 408 MAC); the
+                                       # weight-gradient products dW = dZ^T X of one evaluation cost the same
+FLOP_BWD_CHAIN_8x256 = 1115392         # dH = W^T dZ through rgb, views (feature part), feature + alpha, trunk 7..1
 PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0                  # MI355X HBM3E peak
 MEASURED_HBM_WRITE_GBS = 5900.0        # streaming-write ceiling measured on this pool (tools/membench.hip)
-ACT_BYTES_PER_POINT = 5056 + 320 + 16  # bytes one 8x256 evaluation writes in training mode
-PMC_BYTES_PER_POINT = 5401.0           # measured (WRITE_SIZE + 2 FETCH_SIZE) / points, profiles/*pmc_hbm_bytes*.csv
+MEASURED_HBM_READ_GBS = 6200.0         # streaming-read ceiling, same tool
+# HBM bytes per point-evaluation of an 8x256 network, by saved-tensor format (see ACT_FORMATS):
+#   forward writes the saved activations + 320 B of ReLU bit words + 16 B of raw output,
+#   the backward chain writes dZ and reads the bit words and 16 B of d_raw,
+#   the weight-gradient products read every dZ tensor and every layer input once
+#   (gamma(x) twice: first layer and skip layer; h_7 and dOut shared by feature / alpha).
+ACT_FEATS, DZ_FEATS = 2528, 2464               # features saved by the forward / written by the backward chain per point
+GEMM_DZ_FEATS, GEMM_ACT_FEATS = 2496, 2592     # features the 11 products read per point (dZ side, layer-input side)
+ACT_FORMATS = {"bf16": (2, 2), "fp8": (1, 2), "fp8bf8": (1, 1)}      # bytes per saved activation, per dZ element
+# k_dw_gemm's measured HBM bytes per point ((WRITE_SIZE + 2 x FETCH_SIZE) / points of a launch), from
+# separate rocprofv3 --pmc passes of this command; formats without a pass report traffic null
+PMC_DW_BYTES_PER_POINT = {"bf16": 10206.0}
+PMC_SOURCE = "profiles/r02_kernel_table.csv (separate rocprofv3 --pmc passes of this command), not counted in this run"
 EV = dict(fwd_c0=0, fwd_c1=1, fwd_f0=2, fwd_f1=3, bwd_fchain0=4, bwd_fchain1=5, bwd_fgemm1=6, bwd_cchain0=7,
           bwd_cchain1=8, bwd_end=9)
 
@@ -65,6 +81,10 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays in the CPU baseline sample")
     ap.add_argument("--no-extras", action="store_true", help="skip value_r1024 and heldout_psnr")
     ap.add_argument("--psnr-iters", type=int, default=2000)
+    ap.add_argument("--long-steps", type=int, default=200, help="steps of the value_long leg")
+    ap.add_argument("--act-format", choices=tuple(ACT_FORMATS), default="bf16",
+                    help="format of the tensors saved for backward: bf16 (default), fp8 = e4m3 activations, "
+                         "fp8bf8 = e4m3 activations and e5m2 dZ (experiments, off by default)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous, barrier and the one JSON line only, no GPU work (CPU test of the N-rank launch)")
     return ap.parse_args()
@@ -149,7 +169,7 @@ def timed_steps(tr, sampler, steps, warmup, first=0):
     return (time.perf_counter() - t0) / steps
 
 
-def heldout_psnr(nk, scene, dev, iters, rays, seed):
+def heldout_psnr(nk, scene, dev, iters, rays, seed, act_format="bf16"):
     """Train a fresh 8x256 pair for `iters` iterations on the scene's training views and return the
     mean PSNR of the fine map on its held-out views (validation settings: no jitter, no noise)."""
     import torch
@@ -157,7 +177,7 @@ def heldout_psnr(nk, scene, dev, iters, rays, seed):
     from nerf_kinematics_amd.metrics import mse2psnr
     from nerf_kinematics_amd.trainer import Trainer, TrainOpts
     opts = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=rays, perturb=True, radiance_field_noise_std=0.2,
-                     lr=5e-4, seed=seed)
+                     lr=5e-4, seed=seed, act_format=act_format)
     tr = Trainer(nk.ARCH_RUN_NERF, nk.ARCH_RUN_NERF, opts, dev, rays_per_step=rays)
     smp = RaySampler(scene, rays, seed=seed)
     t0 = time.perf_counter()
@@ -170,6 +190,39 @@ def heldout_psnr(nk, scene, dev, iters, rays, seed):
         out = tr.render(scene.rays(int(k), dev))
         vals.append(mse2psnr(float(((out["rgb_fine"] - scene.target(int(k))) ** 2).mean())))
     return sum(vals) / len(vals), train_s
+
+
+def comm_report(tr, dt_rank, steps, world, backend, dev):
+    """Where a multi-rank step's time went (every rank calls it; rank 0 uses the result): the
+    all-reduce time per step from events around the collective(s) of Trainer.step, every rank's own
+    step time, and the collective library's version and settings."""
+    import torch
+    import torch.distributed as dist
+    ar_ms = [sum(b.elapsed_time(e) for b, e in pairs) for pairs in tr.comm_events]
+    mine = torch.tensor([dt_rank / steps * 1e3, sum(ar_ms) / max(len(ar_ms), 1)], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    if backend == "gloo":           # gloo gathers host tensors
+        every = [t.cpu() for t in every]
+        dist.all_gather(every, mine.cpu())
+    else:
+        dist.all_gather(every, mine)
+    ms = [float(t[0]) for t in every]
+    ar = [float(t[1]) for t in every]
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:          # noqa: BLE001 (a build without the binding still reports the rest)
+        ver = f"unknown ({type(e).__name__})"
+    return {"backend": backend, "collective_library": "RCCL " + ver if backend == "nccl" else backend,
+            "allreduce_ms": sum(ar) / world, "allreduce_ms_per_rank": ar,
+            "ms_per_step_per_rank": ms, "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
+            "collectives_per_step": len(tr.comm_events[0]) if tr.comm_events else 0,
+            "split_allreduce": bool(tr._split_allreduce(tr.R)),
+            "gradient_bytes": int(tr.grad.numel()) * 4,
+            "env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                                   "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY",
+                                                   "NK_OVERLAP_ALLREDUCE")},
+            "note": "allreduce_ms: events on the compute stream before the collective is queued and after the "
+                    "stream has been made to wait for it (includes waiting for the slowest rank)"}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -227,7 +280,7 @@ def main():
     scene = teacher_scene(os.path.join(ROOT, "tests", "golden", "lego_lowres3_weights.npz"), a.views, 2, a.res, dev,
                           phase=0.37 * rank)
     opts = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=rays, perturb=True,
-                     radiance_field_noise_std=0.2, lr=5e-4, seed=42)
+                     radiance_field_noise_std=0.2, lr=5e-4, seed=42, act_format=a.act_format)
     tr = Trainer(nk.ARCH_RUN_NERF, nk.ARCH_RUN_NERF, opts, dev, rays_per_step=rays)
     sampler = RaySampler(scene, rays, seed=1234, rank=rank, world=world)
 
@@ -246,6 +299,7 @@ def main():
     for i in range(a.warmup):
         tr.step(*sampler.next(i))
     if world > 1:
+        tr.comm_events = []             # (begin, end) event pairs around the step's collective(s)
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -253,31 +307,56 @@ def main():
         nklib.check(L.nk_set_stage_events(handles[i], n_ev))
         loss = tr.step(*sampler.next(a.warmup + i))
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0      # this rank's own clock, before it waits for the others
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     nklib.check(L.nk_set_stage_events(None, 0))
+    comm = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        comm = comm_report(tr, dt_rank, a.steps, world, backend, dev)
 
     if rank == 0:
         samples = rays * 192 * a.steps * world
         value = samples / dt
         span = lambda x, y: float(np.mean([row[EV[x]].elapsed_time(row[EV[y]]) for row in ev]))
-        t_f, t_c = span("fwd_f0", "fwd_f1"), span("fwd_c0", "fwd_c1")
-        # Roofline kernel: k_mlp_fwd<256,128,4,true>, two launches per step (coarse: 64 evaluations
-        # per ray, fine: 192).  Per point it does 1 186 816 FLOP and writes 5 392 B (5 056 B of bf16
-        # activations + 320 B of ReLU bit words + 16 B of raw output; rays, depths and the L2-resident
-        # weight stream are noise).  Launch duration = mean over both launches of every timed step.
-        k_ms = 0.5 * (t_f + t_c)
-        pts = rays * (64 + 192) / 2.0                           # points per launch, averaged like k_ms
-        flops = pts * FLOP_PER_EVAL_8x256
-        tflops = flops / (k_ms * 1e-3) / 1e12
-        bytes_per_launch = pts * ACT_BYTES_PER_POINT
-        gbs = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        ab, db = ACT_FORMATS[a.act_format]
         shared = rays * 192 <= (1 << 20)                        # weight-gradient products of both networks in one shared launch
+        pts_f, pts_c = rays * 192.0, rays * 64.0
+        pts = 0.5 * (pts_f + pts_c)                              # points per launch, averaged like the durations
+
+        def view(ms, points, flop_per_pt, bytes_per_pt):
+            """One kernel's two rooflines: FLOP and HBM bytes per launch over its mean duration (ms)."""
+            tf = points * flop_per_pt / (ms * 1e-3) / 1e12
+            gb = points * bytes_per_pt / (ms * 1e-3) / 1e9
+            return {"ms": ms, "tflops": tf, "frac_mfma": tf / PEAK_BF16_TFLOPS, "gbs": gb, "frac_hbm": gb / PEAK_HBM_GBS,
+                    "bytes_per_point": bytes_per_pt, "flop_per_point": flop_per_pt}
+
+        fwd_bytes = ACT_FEATS * ab + 320 + 16
+        bwd_bytes = DZ_FEATS * db + 320 + 16
+        dw_bytes = GEMM_DZ_FEATS * db + GEMM_ACT_FEATS * ab
+        per_kernel = {
+            "k_mlp_fwd<256,128,4,true>": dict(view(0.5 * (span("fwd_f0", "fwd_f1") + span("fwd_c0", "fwd_c1")), pts,
+                                                   FLOP_PER_EVAL_8x256, fwd_bytes),
+                                              ms_fine=span("fwd_f0", "fwd_f1"), ms_coarse=span("fwd_c0", "fwd_c1")),
+            "k_mlp_bwd<256,128,8>": dict(view(0.5 * (span("bwd_fchain0", "bwd_fchain1") + span("bwd_cchain0", "bwd_cchain1")),
+                                              pts, FLOP_BWD_CHAIN_8x256, bwd_bytes),
+                                         ms_fine=span("bwd_fchain0", "bwd_fchain1"),
+                                         ms_coarse=span("bwd_cchain0", "bwd_cchain1")),
+        }
+        if shared:      # small batch: the products of both networks ran in ONE launch behind the coarse chain
+            dw = dict(view(span("bwd_cchain1", "bwd_end"), pts_f + pts_c, FLOP_PER_EVAL_8x256, dw_bytes), launches_per_step=1)
+        else:
+            dw = dict(view(0.5 * (span("bwd_fchain1", "bwd_fgemm1") + span("bwd_cchain1", "bwd_end")), pts,
+                           FLOP_PER_EVAL_8x256, dw_bytes),
+                      ms_fine=span("bwd_fchain1", "bwd_fgemm1"), ms_coarse=span("bwd_cchain1", "bwd_end"), launches_per_step=2)
+        per_kernel["k_dw_gemm + k_dw_reduce"] = dw
+        heavy_ms = (per_kernel["k_mlp_fwd<256,128,4,true>"]["ms"] + per_kernel["k_mlp_bwd<256,128,8>"]["ms"]) * 2 + \
+            dw["ms"] * dw["launches_per_step"]
+        step_tflops = value * 3 * FLOP_PER_EVAL_8x256 * 256 / 192 / 1e12 / world
         res = {
             "metric": "ray-samples/sec (train)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -286,50 +365,82 @@ def main():
                                    f"train step (fwd+bwd+Adam), {rays} rays/step/GPU",
                        "rays_per_step_per_gpu": rays, "num_coarse": 64, "num_fine": 128,
                        "mlp_evals_per_s": value / 192 * 256, "final_loss": float(loss),
+                       "saved_tensor_format": a.act_format,
                        "step_path": "Trainer.step -> nk_render_rays_fwd / nk_render_rays_bwd"},
-            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<256,128,4,true> (Embedder + MLP forward, activations saved)",
-                         "achieved": tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_BF16_TFLOPS,
-                         # HBM bytes per launch from the PMC passes kept under profiles/ (WRITE_SIZE +
-                         # 2 x FETCH_SIZE of the fine launch, scaled to this mean launch)
-                         "traffic": pts * PMC_BYTES_PER_POINT,
-                         "kernel_ms": k_ms, "kernel_ms_fine": t_f, "kernel_ms_coarse": t_c, "flop_per_launch": flops,
-                         "hbm": {"achieved": gbs, "unit": "GB/s", "peak": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS,
-                                 "measured_write_ceiling": MEASURED_HBM_WRITE_GBS,
-                                 "frac_of_measured": gbs / MEASURED_HBM_WRITE_GBS, "bytes_per_launch": bytes_per_launch},
-                         "step_train_tflops": value * 3 * FLOP_PER_EVAL_8x256 * 256 / 192 / 1e12,
-                         "step_frac_of_mfma_peak": value * 3 * FLOP_PER_EVAL_8x256 * 256 / 192 / 1e12 / PEAK_BF16_TFLOPS},
-            # the other heavy launches of the same timed steps (ms, mean): backward chains (4 928 + 180 B
-            # per point) and weight-gradient products + reduce (10 688 B read per point)
-            "kernels": {"bwd_chain_fine_ms": span("bwd_fchain0", "bwd_fchain1"),
-                        "bwd_chain_coarse_ms": span("bwd_cchain0", "bwd_cchain1"),
-                        "dw_gemms_fine_ms": None if shared else span("bwd_fchain1", "bwd_fgemm1"),
-                        "dw_gemms_coarse_ms": None if shared else span("bwd_cchain1", "bwd_end"),
-                        "dw_gemms_shared_ms": span("bwd_cchain1", "bwd_end") if shared else None,
-                        "bwd_chain_fine_gbs": rays * 192 * (4928 + 180) / (span("bwd_fchain0", "bwd_fchain1") * 1e-3) / 1e9},
+            # The time-dominant kernel: the weight-gradient launch (k_dw_gemm, all 11 products
+            # dW = dZ^T X of a network, and the k_dw_reduce behind it).  Per point it does the forward's
+            # 1 186 816 FLOP and reads every dZ tensor and every layer input once.
+            "roofline": {"bound": "mfma", "kernel": "k_dw_gemm + k_dw_reduce (weight-gradient products of one network)",
+                         "achieved": dw["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": dw["frac_mfma"],
+                         # HBM bytes per launch were NOT counted in this run: the figure below is
+                         # (WRITE_SIZE + 2 x FETCH_SIZE) per point of the separate rocprofv3 --pmc passes of
+                         # this command kept under profiles/, scaled to this launch; null for formats without a pass
+                         "traffic": (pts if not shared else pts_f + pts_c) * PMC_DW_BYTES_PER_POINT[a.act_format]
+                         if PMC_DW_BYTES_PER_POINT.get(a.act_format) else None,
+                         "traffic_source": PMC_SOURCE if PMC_DW_BYTES_PER_POINT.get(a.act_format) else None,
+                         "kernel_ms": dw["ms"], "flop_per_launch": (pts if not shared else pts_f + pts_c) * FLOP_PER_EVAL_8x256,
+                         "hbm": {"achieved": dw["gbs"], "unit": "GB/s", "peak": PEAK_HBM_GBS, "frac": dw["frac_hbm"],
+                                 "measured_read_ceiling": MEASURED_HBM_READ_GBS,
+                                 "frac_of_measured": dw["gbs"] / MEASURED_HBM_READ_GBS,
+                                 "bytes_per_launch": (pts if not shared else pts_f + pts_c) * dw_bytes},
+                         "per_kernel": per_kernel,
+                         "heavy_kernels_ms_per_step": heavy_ms,
+                         "step_train_tflops": step_tflops,
+                         "step_frac_of_mfma_peak": step_tflops / PEAK_BF16_TFLOPS,
+                         "step_hbm_gbs": rays * 256 * (fwd_bytes + bwd_bytes + dw_bytes) / (dt / a.steps) / 1e9},
         }
-        if world == 1 and not a.no_extras:
-            tr = None
-            torch.cuda.empty_cache()
-            opts1k = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=1024, perturb=True,
-                               radiance_field_noise_std=0.2, lr=5e-4, seed=42)
-            tr1k = Trainer(nk.ARCH_RUN_NERF, nk.ARCH_RUN_NERF, opts1k, dev, rays_per_step=1024)
-            t1k = timed_steps(tr1k, RaySampler(scene, 1024, seed=1234), 300, 30)
-            res["value_r1024"] = {"value": 1024 * 192 / t1k, "unit": "ray-samples/s", "ms_per_step": t1k * 1e3,
-                                  "rays_per_step": 1024, "steps": 300, "warmup": 30}
-            tr1k = None
-            p, train_s = heldout_psnr(nk, scene, dev, a.psnr_iters, 4096, seed=42)
-            res["heldout_psnr"] = {"value": p, "unit": "dB", "iters": a.psnr_iters, "rays_per_step": 4096, "seed": 42,
-                                   "train_views": a.views, "heldout_views": 2, "train_seconds": train_s,
-                                   "note": "fresh 8x256 pair on the lego-teacher views, fine map, validation settings"}
-        if world == 1 and not a.no_cpu_baseline:
-            torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
-            from oracle import nerf_oracle as O        # the CPU restatement is only ever the baseline leg
-            v, t = cpu_baseline(O, a.cpu_rays)
-            res["cpu_baseline"] = {"value": v, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
-                                   "kind": "port",
-                                   "sample": f"{a.cpu_rays} rays x (64+128) samples, one training step "
-                                             f"(fwd+bwd+Adam) of the torch-CPU fp32 restatement, median of 3 "
-                                             f"after 1 warm-up, {t:.2f} s/step"}
+        if comm is not None:
+            res["comm"] = comm
+    if world == 1 and not a.no_extras:
+        # the same step over a longer timed region
+        n_long = max(a.long_steps, 1)
+        t_long = timed_steps(tr, sampler, n_long, 0, first=a.warmup + a.steps)
+        res["value_long"] = {"value": rays * 192 / t_long, "unit": "ray-samples/s", "ms_per_step": t_long * 1e3,
+                             "steps": n_long}
+        # whole-image inference: one 400x400 view, nerf.validation settings (k_mlp_fwd<...,false>)
+        rb = scene.rays(int(scene.i_val[0]), dev)
+        tr.render(rb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tr.render(rb)
+        torch.cuda.synchronize()
+        t_img = (time.perf_counter() - t0) / 5
+        res["render_400x400_ms"] = {"value": t_img * 1e3, "unit": "ms", "rays": int(rb.shape[0]), "repeats": 5,
+                                    "rays_per_s": rb.shape[0] / t_img,
+                                    "mfma_frac": rb.shape[0] * 256 * FLOP_PER_EVAL_8x256 / t_img / 1e12 / PEAK_BF16_TFLOPS,
+                                    "note": "Trainer.render: 64+128 samples, no jitter, no noise, nothing saved"}
+        tr = None
+        torch.cuda.empty_cache()
+        opts1k = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=1024, perturb=True,
+                           radiance_field_noise_std=0.2, lr=5e-4, seed=42, act_format=a.act_format)
+        tr1k = Trainer(nk.ARCH_RUN_NERF, nk.ARCH_RUN_NERF, opts1k, dev, rays_per_step=1024)
+        t1k = timed_steps(tr1k, RaySampler(scene, 1024, seed=1234), 300, 30)
+        res["value_r1024"] = {"value": 1024 * 192 / t1k, "unit": "ray-samples/s", "ms_per_step": t1k * 1e3,
+                              "rays_per_step": 1024, "steps": 300, "warmup": 30}
+        tr1k = None
+        p, train_s = heldout_psnr(nk, scene, dev, a.psnr_iters, 4096, seed=42, act_format=a.act_format)
+        res["heldout_psnr"] = {"value": p, "unit": "dB", "iters": a.psnr_iters, "rays_per_step": 4096, "seed": 42,
+                               "train_views": a.views, "heldout_views": 2, "train_seconds": train_s,
+                               "note": "fresh 8x256 pair on the lego-teacher views, fine map, validation settings"}
+    if world == 1 and not a.no_cpu_baseline:
+        # Threads: the CPUs this process may run on, capped by the box's own OMP_NUM_THREADS (the GPU
+        # boxes of this pool show the whole machine in os.cpu_count() but grant a share of it).
+        host_cores = os.cpu_count() or 1
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores
+        cap = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+        threads = min(usable, cap) if cap > 0 else usable
+        torch.set_num_threads(threads)
+        from oracle import nerf_oracle as O        # the CPU restatement is only ever the baseline leg
+        v, t = cpu_baseline(O, a.cpu_rays)
+        res["cpu_baseline"] = {"value": v, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
+                               "kind": "port", "host_cores": host_cores, "usable_cores": usable,
+                               "threads": torch.get_num_threads(),
+                               "sample": f"{a.cpu_rays} of the step's {rays} rays x (64+128) samples, one training step "
+                                         f"(fwd+bwd+Adam) of the torch-CPU fp32 restatement, median of 3 "
+                                         f"after 1 warm-up, {t:.2f} s/step; threads = min(CPUs this process may "
+                                         f"use, OMP_NUM_THREADS)"}
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -70,6 +70,16 @@ typedef struct nk_step_state {
     int32_t  reserved;
 } nk_step_state;
 
+/* Formats of the tensors a training forward saves for backward (nk_render_opts.act_format).
+ * No counterpart in the reference (torch autograd keeps fp32 activations).  NK_ACT_BF16 is the
+ * default; the two 8-bit forms are experiments that halve the bytes the training step moves
+ * through HBM at the price of a coarser weight gradient:
+ *   NK_ACT_FP8      layer inputs saved as OCP e4m3 (rounded once from the fp32 accumulator; the forward
+ *                   chain itself still runs on bf16 operands, so outputs do not change), dZ as bf16
+ *   NK_ACT_FP8_BF8  the same, and dZ saved as OCP e5m2 scaled by a power of two that the weight-gradient
+ *                   reduction divides out again (the backward chain itself still runs on bf16)      */
+enum { NK_ACT_BF16 = 0, NK_ACT_FP8 = 1, NK_ACT_FP8_BF8 = 2 };
+
 /* nerf.train / nerf.validation of config.yml:46-63 */
 typedef struct nk_render_opts {
     int32_t num_coarse;
@@ -79,9 +89,15 @@ typedef struct nk_render_opts {
     int32_t white_background;
     float   radiance_field_noise_std;
     uint32_t seed;                /* seed of the counter-based RNG streams                */
-    int32_t  reserved;
+    int32_t  act_format;          /* NK_ACT_*: training calls only; forward and backward must agree */
     const nk_step_state* state;   /* device pointer or NULL; when set, the kernels take the seed
                                      from state->render_seed when they run and `seed` is ignored */
+    float    skip_empty_eps;      /* inference calls only (ignored when training): > 0 skips the fine
+                                     network for every group of 32 consecutive fine samples whose
+                                     neighbouring coarse samples all have compositing weight below this
+                                     value; their rows are emitted with zero density.  0 = evaluate
+                                     every sample (the reference's behaviour).  Experiment.          */
+    int32_t  reserved;
 } nk_render_opts;
 
 /* Camera for nk_get_rays: intrinsics as in transforms.json (fl_x, fl_y, cx, cy) and a 3x4

@@ -2,6 +2,7 @@
 // workspace.  Mirrors the body of nerf-pytorch's render_rays (coarse pass, sample_pdf, fine pass)
 // with the knobs of the nerf.train / nerf.validation blocks of the reference experiment files
 // (/root/reference/trained_models/nerf-pytorch/lego-lowres3/config.yml:46-63).
+#include <math.h>
 #include <string.h>
 #include <mutex>
 #include "nk_common.h"
@@ -14,8 +15,18 @@ static __device__ __align__(256) unsigned char scratch[NK_NOALLOC_SCRATCH_BYTES]
 namespace {
 
 struct WsLayout {
-    int64_t z_c, raw_c, w_c, rgb_c_tmp, z_all, raw_f, act_c, act_f, d_raw, dz, dz_c, total;
+    int64_t z_c, raw_c, w_c, rgb_c_tmp, z_all, raw_f, live, act_c, act_f, d_raw, dz, dz_c, total;
 };
+
+// nk_render_opts.skip_empty_eps applies to inference calls with a fine pass
+inline bool skips_empty(const nk_render_opts* o, int training) { return !training && o->num_fine > 0 && o->skip_empty_eps > 0.0f; }
+
+// NK_ACT_FP8_BF8: the power of two dZ is multiplied by before it is rounded to e5m2.  d(loss)/d(rgb)
+// of a mean-squared error over R rays is at most 2/(3R) per component, so with 2^(ceil(log2 R) + 6)
+// the largest dZ of the output layer is about 43 and the chain has a factor 1 300 of headroom below
+// the e5m2 maximum (57 344; conversions saturate there), while e5m2's 32 binades reach down to
+// gradients 2^-30 of that size.
+inline float dz_scale_for(int64_t R) { return ldexpf(1.0f, (int)ceil(log2((double)R)) + 6); }
 
 constexpr int64_t NK_PAIR_GEMM_MAX_POINTS = 1 << 20;
 
@@ -26,25 +37,30 @@ int layout(const nk_arch* ac, const nk_arch* af, const nk_render_opts* o, int64_
     const int Nc = o->num_coarse, Nf = o->num_fine, N = Nc + Nf;
     if (Nc < 2 || Nf < 0) NK_FAIL(NK_ERR_ARG, "render workspace: num_coarse=%d num_fine=%d", Nc, Nf);
     if (Nf > 0 && !af) NK_FAIL(NK_ERR_ARG, "render workspace: num_fine > 0 needs a fine network");
+    const int fmt = training ? o->act_format : NK_ACT_BF16;
+    if (fmt < NK_ACT_BF16 || fmt > NK_ACT_FP8_BF8) NK_FAIL(NK_ERR_ARG, "render workspace: unknown act_format %d", fmt);
+    if (!(o->skip_empty_eps >= 0.0f)) NK_FAIL(NK_ERR_ARG, "render workspace: skip_empty_eps must be >= 0");
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t at = off; off = align256(off + bytes); return at; };
     L->z_c = take(R * Nc * 4);
     L->raw_c = take(R * Nc * 16);
     L->w_c = take(R * Nc * 4);
     L->rgb_c_tmp = take(R * 12);
-    L->z_all = L->raw_f = L->act_c = L->act_f = L->d_raw = L->dz = L->dz_c = -1;
+    L->z_all = L->raw_f = L->live = L->act_c = L->act_f = L->d_raw = L->dz = L->dz_c = -1;
     if (Nf > 0) { L->z_all = take(R * N * 4); L->raw_f = take(R * N * 16); }
+    // skip_empty_eps: a counter (first 256 bytes) and the list of the fine groups to evaluate
+    if (skips_empty(o, training)) L->live = take(256 + nk_groups(R * (int64_t)N) * 4);
     if (training) {
-        int64_t b = nk_act_bytes(ac, R, Nc);
+        int64_t b = nk_act_bytes_fmt(ac, R, Nc, fmt);
         if (b < 0) return (int)b;
         L->act_c = take(b);
-        int64_t dzb = nk_dz_bytes(ac, R, Nc);
+        int64_t dzb = nk_dz_bytes_fmt(ac, R, Nc, fmt);
         if (dzb < 0) return (int)dzb;
         if (Nf > 0) {
-            b = nk_act_bytes(af, R, N);
+            b = nk_act_bytes_fmt(af, R, N, fmt);
             if (b < 0) return (int)b;
             L->act_f = take(b);
-            const int64_t d2 = nk_dz_bytes(af, R, N);
+            const int64_t d2 = nk_dz_bytes_fmt(af, R, N, fmt);
             if (d2 < 0) return (int)d2;
             if (d2 > dzb) dzb = d2;
         }
@@ -53,7 +69,7 @@ int layout(const nk_arch* ac, const nk_arch* af, const nk_render_opts* o, int64_
         // Small batches: the coarse network gets a dZ region of its own, so that the weight-gradient
         // GEMMs of both networks can run in one shared launch after both chains (one network's
         // products alone leave most of the chip idle).  Large batches reuse one region in turn.
-        if (Nf > 0 && R * (int64_t)N <= NK_PAIR_GEMM_MAX_POINTS) L->dz_c = take(nk_dz_bytes(ac, R, Nc));
+        if (Nf > 0 && R * (int64_t)N <= NK_PAIR_GEMM_MAX_POINTS) L->dz_c = take(nk_dz_bytes_fmt(ac, R, Nc, fmt));
     }
     L->total = off;
     return NK_OK;
@@ -130,15 +146,27 @@ extern "C" int nk_render_rays_fwd(const nk_arch* ac, const void* pc, const nk_ar
 
     if ((rc = nk_stratified_z(ray_batch, R, o, z_c, stream)) < 0) return rc;
     if ((rc = mark(NK_EV_FWD_COARSE_BEGIN, stream)) < 0) return rc;
-    if ((rc = nk_mlp_forward(ac, pc, ray_batch, z_c, R, Nc, raw_c, training ? ws + L.act_c : nullptr, stream)) < 0) return rc;
+    const int fmt = training ? o->act_format : NK_ACT_BF16;
+    if ((rc = nk_mlp_forward_fmt(ac, pc, ray_batch, z_c, R, Nc, raw_c, training ? ws + L.act_c : nullptr, fmt, nullptr, nullptr,
+                                 stream)) < 0) return rc;
     if ((rc = mark(NK_EV_FWD_COARSE_END, stream)) < 0) return rc;
     if ((rc = nk_raw2outputs(raw_c, z_c, ray_batch, R, Nc, o, NK_STREAM_NOISE_COARSE, rgb_c, out->disp_coarse,
                              out->acc_coarse, out->depth_coarse, w_c, stream)) < 0) return rc;
     if (Nf > 0) {
         float* z_all = (float*)(ws + L.z_all); float* raw_f = (float*)(ws + L.raw_f);
         if ((rc = nk_sample_pdf(z_c, w_c, R, o, z_all, nullptr, stream)) < 0) return rc;
+        const int32_t* live = nullptr;
+        const int32_t* n_live = nullptr;
+        if (L.live >= 0) {
+            // groups of 32 fine samples near which the coarse pass saw nothing get zero-density rows
+            // here and are left out of the fine network's launch
+            n_live = (const int32_t*)(ws + L.live); live = (const int32_t*)(ws + L.live + 256);
+            if ((rc = nk_mark_live_groups(z_c, w_c, z_all, R, Nc, N, o->skip_empty_eps, (int32_t*)live, (int32_t*)n_live, raw_f,
+                                          stream)) < 0) return rc;
+        }
         if ((rc = mark(NK_EV_FWD_FINE_BEGIN, stream)) < 0) return rc;
-        if ((rc = nk_mlp_forward(af, pf, ray_batch, z_all, R, N, raw_f, training ? ws + L.act_f : nullptr, stream)) < 0) return rc;
+        if ((rc = nk_mlp_forward_fmt(af, pf, ray_batch, z_all, R, N, raw_f, training ? ws + L.act_f : nullptr, fmt, live, n_live,
+                                     stream)) < 0) return rc;
         if ((rc = mark(NK_EV_FWD_FINE_END, stream)) < 0) return rc;
         if ((rc = nk_raw2outputs(raw_f, z_all, ray_batch, R, N, o, NK_STREAM_NOISE_FINE, out->rgb_fine, out->disp_fine,
                                  out->acc_fine, out->depth_fine, nullptr, stream)) < 0) return rc;
@@ -163,8 +191,9 @@ extern "C" int nk_render_rays_bwd(const nk_arch* ac, const void* pc, const nk_ar
     const bool fine = Nf > 0 && d_rgb_fine, coarse = d_rgb_coarse != nullptr;
     if (fine && (!pf || !grad_fine)) NK_FAIL(NK_ERR_ARG, "nk_render_rays_bwd: fine gradient requested without packed_fine / grad_fine");
     if (coarse && !grad_coarse) NK_FAIL(NK_ERR_ARG, "nk_render_rays_bwd: coarse gradient requested without grad_coarse");
-    const NkBwdJob jf = {af, pf, ws + L.act_f, d_raw, R, N, ws + L.dz, grad_fine};
-    const NkBwdJob jc = {ac, pc, ws + L.act_c, d_raw, R, Nc, ws + (L.dz_c >= 0 ? L.dz_c : L.dz), grad_coarse};
+    const float dz_scale = o->act_format == NK_ACT_FP8_BF8 ? dz_scale_for(R) : 1.0f;
+    const NkBwdJob jf = {af, pf, ws + L.act_f, d_raw, R, N, ws + L.dz, grad_fine, o->act_format, dz_scale};
+    const NkBwdJob jc = {ac, pc, ws + L.act_c, d_raw, R, Nc, ws + (L.dz_c >= 0 ? L.dz_c : L.dz), grad_coarse, o->act_format, dz_scale};
     const bool together = fine && coarse && L.dz_c >= 0;
     if (fine) {
         if ((rc = nk_raw2outputs_bwd((float*)(ws + L.raw_f), (float*)(ws + L.z_all), ray_batch, R, N, o,

@@ -104,8 +104,11 @@ struct NkPlan {
     int n_params;
 };
 
-// Activation regions saved by the forward pass, each [G][width/8][32][8] bf16 (the encodings in
-// slot order, the layer outputs with every 32-feature tile in nk_tile_feature() order).
+// Activation regions saved by the forward pass.  Two element formats (eb = bytes per element):
+//   eb = 2  [G][width/8][32][8] bf16: the encodings in slot order, the layer outputs with every
+//           32-feature tile in nk_tile_feature() order;
+//   eb = 1  [G][width/16][32][16] OCP e4m3 (NK_ACT_FP8*): the encodings in slot order, layer outputs
+//           with every 32-feature tile in nk_tile_feature8() order.
 // index: 0 = gamma(x) slots (64), 1 = gamma(d) slots (32), 2+i = h_i (W), 2+D = feat (W), 3+D = g (WD)
 NK_HD int nk_act_width(const NkPlan& p, int idx) {
     if (idx == 0) return 64;
@@ -113,12 +116,15 @@ NK_HD int nk_act_width(const NkPlan& p, int idx) {
     if (idx < 2 + p.D + 1) return p.W;
     return p.WD;
 }
-NK_HD int64_t nk_act_offset(const NkPlan& p, int idx, int64_t G) {   // bytes
+NK_HD int64_t nk_act_offset(const NkPlan& p, int idx, int64_t G, int eb = 2) {   // bytes
     int64_t feats = 0;
     for (int i = 0; i < idx; ++i) feats += nk_act_width(p, i);
-    return feats * G * 64;      // 32 points * 2 bytes
+    return feats * G * 32 * eb;      // 32 points * eb bytes
 }
 NK_HD int nk_act_count(const NkPlan& p) { return p.D + 4; }
+// element bytes of the saved activations / of dZ under an NK_ACT_* format
+NK_HD int nk_act_elem_bytes(int act_format) { return act_format == NK_ACT_BF16 ? 2 : 1; }
+NK_HD int nk_dz_elem_bytes(int act_format) { return act_format == NK_ACT_FP8_BF8 ? 1 : 2; }
 
 // Feature (row of the 32-row tile) held at position x = 8 * octet + e of a saved activation / dZ
 // tile: the chain kernels store a converted accumulator fragment as it lies in registers (one
@@ -127,14 +133,20 @@ NK_HD int nk_tile_feature(int x) {
     const int o = x >> 3, e = x & 7;
     return 16 * (o >> 1) + 8 * (e >> 2) + 4 * (o & 1) + (e & 3);
 }
+// The same for the 8-bit formats: a lane stores its 16 accumulator registers of a tile as ONE
+// 16-byte piece, position x = 16 * h + e holds register e of lane-half h.
+NK_HD int nk_tile_feature8(int x) {
+    const int h = x >> 4, e = x & 15;
+    return 8 * (e >> 2) + 4 * h + (e & 3);
+}
 
 // ReLU masks, one 16-byte word per lane per layer ([G][64 lanes][4 dwords]), stored after the
 // activation regions: idx 0..D-1 = h_i, D = feat, D+1 = g.  Bit 31 - (16*(t&1) + i) of dword t>>1
 // is set when accumulator register i of output tile t passes its gradient (sign bit of the
 // pre-activation clear, or the layer has no ReLU).
 NK_HD int nk_mask_count(const NkPlan& p) { return p.D + 2; }
-NK_HD int64_t nk_mask_offset(const NkPlan& p, int idx, int64_t G) {
-    return nk_act_offset(p, nk_act_count(p), G) + (int64_t)idx * G * 1024;
+NK_HD int64_t nk_mask_offset(const NkPlan& p, int idx, int64_t G, int eb = 2) {
+    return nk_act_offset(p, nk_act_count(p), G, eb) + (int64_t)idx * G * 1024;
 }
 
 // dZ regions written by the backward chain: 0 = dOut (32: dr,dg,db,dsigma), 1 = dZ_views (WD),
@@ -144,10 +156,10 @@ NK_HD int nk_dz_width(const NkPlan& p, int idx) {
     if (idx == 1) return p.WD;
     return p.W;
 }
-NK_HD int64_t nk_dz_offset(const NkPlan& p, int idx, int64_t G) {
+NK_HD int64_t nk_dz_offset(const NkPlan& p, int idx, int64_t G, int eb = 2) {   // eb = 1: OCP e5m2, laid out like 8-bit activations
     int64_t feats = 0;
     for (int i = 0; i < idx; ++i) feats += nk_dz_width(p, i);
-    return feats * G * 64;
+    return feats * G * 32 * eb;
 }
 NK_HD int nk_dz_count(const NkPlan& p) { return p.D + 3; }
 
@@ -169,6 +181,20 @@ int nk_waves_per_wg(int backward);
 struct NkBwdJob {
     const nk_arch* arch; const void* packed; const void* act; const float* d_raw;
     int64_t R; int32_t n; void* dz; float* grad;
+    int act_format;         // NK_ACT_*: format of `act` (as the forward call saved it) and of `dz`
+    float dz_scale;         // NK_ACT_FP8_BF8: power of two dZ is scaled by before it is rounded to e5m2
 };
 int nk_mlp_backward_chain(const NkBwdJob& job, hipStream_t stream);
 int nk_mlp_backward_gemms(const NkBwdJob* jobs, int count, hipStream_t stream);
+// nk_mlp_forward / nk_act_bytes / nk_dz_bytes with the saved-tensor format named
+int nk_mlp_forward_fmt(const nk_arch* arch, const void* packed, const float* ray_batch, const float* z, int64_t R,
+                       int32_t n, float* raw, void* act_save, int act_format, const int32_t* live_groups,
+                       const int32_t* n_live, void* stream);
+// Occupancy skipping (nk_render_opts.skip_empty_eps): lists in live[] the groups of 32 consecutive
+// fine samples (points of z_all, [R, N]) that have a sample whose four nearest coarse samples reach
+// compositing weight eps, counts them in *n_live, and writes zero rows (rgb_raw = 0, sigma_raw = 0)
+// to raw_f for the others.
+int nk_mark_live_groups(const float* z_coarse, const float* w_coarse, const float* z_all, int64_t R, int32_t Nc,
+                        int32_t N, float eps, int32_t* live, int32_t* n_live, float* raw_f, void* stream);
+int64_t nk_act_bytes_fmt(const nk_arch* arch, int64_t R, int32_t n, int act_format);
+int64_t nk_dz_bytes_fmt(const nk_arch* arch, int64_t R, int32_t n, int act_format);

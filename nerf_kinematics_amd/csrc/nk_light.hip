@@ -505,6 +505,54 @@ extern "C" int nk_sample_pdf(const float* z_coarse, const float* weights, int64_
 }
 
 // ============================================================================================
+// occupancy skipping (inference experiment; no counterpart in the reference, which evaluates the
+// fine network on every sample)
+// ============================================================================================
+// One thread per fine sample, 32 consecutive samples = one group of the fine network's launch.  A
+// sample is "near something" when one of the four coarse samples around its depth (two on either
+// side) has compositing weight >= eps; a group with no such sample gets zero rows in raw_f and is
+// left out of the list.  The list is filled through a counter, so its order varies from run to run;
+// the rendered values do not depend on it (every listed group is evaluated on its own).
+__global__ __launch_bounds__(256) void k_mark_live_groups(const float* __restrict__ zc, const float* __restrict__ wc,
+                                                          const float* __restrict__ z_all, int64_t P, int Nc, int N, float eps,
+                                                          int32_t* __restrict__ live, int32_t* __restrict__ n_live,
+                                                          float* __restrict__ raw_f) {
+    const int64_t pt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool near = false;
+    if (pt < P) {
+        const int64_t ray = pt / N;
+        const float* z = zc + ray * Nc;
+        const float* w = wc + ray * Nc;
+        const float v = z_all[pt];
+        int lo = 0, hi = Nc;                             // coarse depths not above v
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (z[mid] <= v) lo = mid + 1; else hi = mid; }
+        // coarse samples lo-2 .. lo+1 (v lies between lo-1 and lo)
+        for (int k = lo - 2; k <= lo + 1; ++k)
+            if (k >= 0 && k < Nc && w[k] >= eps) near = true;
+    }
+    const uint64_t vote = __ballot(near);
+    const int half = (threadIdx.x >> 5) & 1;
+    const bool group_live = ((vote >> (32 * half)) & 0xFFFFFFFFull) != 0;
+    if (group_live) {
+        if ((threadIdx.x & 31) == 0) live[atomicAdd(n_live, 1)] = (int32_t)(pt >> 5);
+    } else if (pt < P) {
+        *(float4*)(raw_f + pt * 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+int nk_mark_live_groups(const float* z_coarse, const float* w_coarse, const float* z_all, int64_t R, int32_t Nc,
+                        int32_t N, float eps, int32_t* live, int32_t* n_live, float* raw_f, void* stream) {
+    if (!z_coarse || !w_coarse || !z_all || !live || !n_live || !raw_f || R <= 0 || Nc < 2 || N <= Nc)
+        NK_FAIL(NK_ERR_ARG, "nk_mark_live_groups: null pointer or bad size");
+    const int64_t P = R * (int64_t)N;
+    NK_CHECK_HIP(hipMemsetAsync(n_live, 0, 4, nk_stream(stream)));
+    hipLaunchKernelGGL(k_mark_live_groups, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, nk_stream(stream), z_coarse,
+                       w_coarse, z_all, P, (int)Nc, (int)N, eps, live, n_live, raw_f);
+    NK_CHECK_LAUNCH("k_mark_live_groups");
+    return NK_OK;
+}
+
+// ============================================================================================
 // loss and optimiser
 // ============================================================================================
 __global__ __launch_bounds__(256) void k_mse_loss(const float* __restrict__ rc, const float* __restrict__ rf,

@@ -21,8 +21,24 @@ NK_D void sincos_rev(float x, float& s, float& c) {
     c = __builtin_amdgcn_cosf(r);
 }
 
-// gamma(x) as 4 B-operand fragments (k-slots per nk_pe_xyz_col)
-NK_D void pe_xyz_frags(float px, float py, float pz, int h, Frag (&f)[4]) {
+// Two fp32 values -> two OCP e4m3 bytes in the low (hi = false) or high half of `old`; rounds to
+// nearest even, and with MODE.FP16_OVFL set (nk_fp8_saturate) values beyond +-448 give +-448.
+NK_D uint32_t pk_fp8(float a, float b, uint32_t old, bool hi) {
+    return (uint32_t)(hi ? __builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, true)
+                         : __builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, false));
+}
+// ... and OCP e5m2 (saturates at +-57344 under the same mode bit)
+NK_D uint32_t pk_bf8(float a, float b, uint32_t old, bool hi) {
+    return (uint32_t)(hi ? __builtin_amdgcn_cvt_pk_bf8_f32(a, b, (int)old, true)
+                         : __builtin_amdgcn_cvt_pk_bf8_f32(a, b, (int)old, false));
+}
+// MODE.FP16_OVFL = 1 for the rest of the wave's life: 8-bit float conversions saturate instead of
+// producing NaN (e4m3) or infinity (e5m2).  hwreg(MODE, offset 23, width 1).
+NK_D void nk_fp8_saturate() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
+
+// gamma(x) as 4 B-operand fragments (k-slots per nk_pe_xyz_col); p8 (optional): the same 32 slots
+// as e4m3 bytes, dwords 2s, 2s+1 = k-step s
+NK_D void pe_xyz_frags(float px, float py, float pz, int h, Frag (&f)[4], uint32_t* p8 = nullptr) {
     float v[32];
     const float base = h ? 32.0f : 1.0f;
 #pragma unroll
@@ -38,10 +54,14 @@ NK_D void pe_xyz_frags(float px, float py, float pz, int h, Frag (&f)[4]) {
     for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int w = 0; w < 4; ++w) f[s].u[w] = pack_bf16(v[8 * s + 2 * w], v[8 * s + 2 * w + 1]);
+    if (p8) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) p8[d] = pk_fp8(v[4 * d + 2], v[4 * d + 3], pk_fp8(v[4 * d], v[4 * d + 1], 0, false), true);
+    }
 }
 
-// gamma(d) as 2 fragments (k-slots per nk_pe_dir_col)
-NK_D void pe_dir_frags(float dx, float dy, float dz, int h, Frag (&f)[2]) {
+// gamma(d) as 2 fragments (k-slots per nk_pe_dir_col); p8 (optional): e4m3 bytes, dwords 2s, 2s+1 = k-step s
+NK_D void pe_dir_frags(float dx, float dy, float dz, int h, Frag (&f)[2], uint32_t* p8 = nullptr) {
     float v[16];
     const float base = h ? 4.0f : 1.0f;
 #pragma unroll
@@ -58,6 +78,10 @@ NK_D void pe_dir_frags(float dx, float dy, float dz, int h, Frag (&f)[2]) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int w = 0; w < 4; ++w) f[s].u[w] = pack_bf16(v[8 * s + 2 * w], v[8 * s + 2 * w + 1]);
+    if (p8) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) p8[d] = pk_fp8(v[4 * d + 2], v[4 * d + 3], pk_fp8(v[4 * d], v[4 * d + 1], 0, false), true);
+    }
 }
 
 // The weight stream: stage i sits in LDS ring slot i % 3 and is loaded (LDS-DMA, 16 B per lane)
@@ -239,6 +263,7 @@ NK_D void save_tile(char* dst, int64_t grp, int NO, int t, int c, int h, const F
 }
 
 NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1);
+NK_D void acc_to_frags8(const f32x16& a, bool relu, Frag& f0, Frag& f1, Frag& s8);
 
 // max(x, 0) as ONE instruction, v_max_i32 on the bit pattern (negative floats are negative
 // integers; -0 and NaNs with the sign bit set give +0, other NaNs pass).  fmaxf() costs two:
@@ -255,8 +280,10 @@ NK_D float relu1(float x) {
 // The forward kernel stores ~mw for a ReLU layer (all ones otherwise) as the layer's
 // pass-gradient word: a gradient passes where the pre-activation's sign bit is clear.  That is
 // relu'(x) everywhere except at x == +0 exactly, where torch blocks the gradient.
-template <bool MASK>
-NK_D void acc_to_frags_mask(const f32x16& a, bool relu, Frag& f0, Frag& f1, uint32_t& mw) {
+// S8: also the tile as sixteen e4m3 bytes in s8 (byte e = accumulator register e, rounded once
+// from the fp32 value after the ReLU) -- what the forward kernel saves under NK_ACT_FP8*.
+template <bool MASK, bool S8 = false>
+NK_D void acc_to_frags_mask(const f32x16& a, bool relu, Frag& f0, Frag& f1, uint32_t& mw, Frag* s8 = nullptr) {
     if (!MASK) { acc_to_frags(a, relu, f0, f1); return; }
     // (never __builtin_bit_cast a vector ELEMENT: hipcc reads the wrong lane of it)
     // registers are visited in index order 0..15 so that bit 31-k of the word belongs to register k
@@ -268,7 +295,8 @@ NK_D void acc_to_frags_mask(const f32x16& a, bool relu, Frag& f0, Frag& f1, uint
     }
     asm volatile("" : "+v"(m));     // computed here: otherwise it is sunk to the layer's end and
     mw = m;                         // keeps every accumulator tile of the layer alive (spills)
-    acc_to_frags(a, relu, f0, f1);
+    if constexpr (S8) acc_to_frags8(a, relu, f0, f1, *s8);
+    else acc_to_frags(a, relu, f0, f1);
 }
 
 // ReLU of two packed bf16 values in one instruction: v_pk_max_i16 against 0 on the bit patterns
@@ -311,3 +339,19 @@ NK_D void acc_to_frags(const f32x16& a, bool relu, Frag& f0, Frag& f1) {
 #endif
 }
 
+NK_D void acc_to_frags8(const f32x16& a, bool relu, Frag& f0, Frag& f1, Frag& s8) {
+    // four registers at a time: two bf16 pairs (dwords of f0 / f1) and one dword of e4m3 bytes
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        float x0 = a[4 * w], x1 = a[4 * w + 1], x2 = a[4 * w + 2], x3 = a[4 * w + 3];
+        if (relu) { x0 = relu1(x0); x1 = relu1(x1); x2 = relu1(x2); x3 = relu1(x3); }
+        Frag& f = w < 2 ? f0 : f1;
+        f.u[2 * (w & 1)] = pack_bf16(x0, x1);
+        f.u[2 * (w & 1) + 1] = pack_bf16(x2, x3);
+        uint32_t d = pk_fp8(x2, x3, pk_fp8(x0, x1, 0, false), true);
+        // computed here: left to itself hipcc holds all sixteen ReLU results back and converts them
+        // late, which costs the forward kernel 45 spilled registers
+        asm volatile("" : "+v"(d), "+v"(f.u[2 * (w & 1)]), "+v"(f.u[2 * (w & 1) + 1]));
+        s8.u[w] = d;
+    }
+}

@@ -22,6 +22,8 @@ struct BwdArgs {
     char* dz;               // dZ regions
     int64_t P, G;
     int stagger;            // upper half of each workgroup's waves run the staggered stage order
+    int act_eb;             // bytes per saved-activation element (places the ReLU bit words behind them)
+    float dz_scale;         // e5m2 dZ only: power of two applied to d_raw on the way in
 };
 
 #include "nk_bwd_chain.inc"
@@ -64,6 +66,8 @@ struct GemmOut {
     int MA0, NB0;
     int mt, nt, wn;                 // tile counts of the product and waves across a tile row
     int n_slices;
+    int row8, col8;                 // A / B regions are 8-bit: their tiles keep features in nk_tile_feature8() order
+    float scale;                    // the sums are multiplied by this (1, or 1 / the dZ scale of e5m2 dZ)
     int64_t partial_off;
     float* grad;                    // flat gradient
 };
@@ -96,6 +100,53 @@ NK_D bf16x8 tr_value(const TrFrag& f) {
     const u32x4 u = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
     return __builtin_bit_cast(bf16x8, u);
 }
+
+// The same for 8-bit regions ([16-feature piece][point][16] bytes, one tile = pieces 2*tile and
+// 2*tile + 1): ONE ds_read_b64_tr_b8 is a whole MFMA operand.  Per group of 16 lanes the
+// instruction reads a block of 8 rows (points) x 16 columns (features) of bytes -- lane 2q + p of the
+// group supplies the address of row q, columns 8p .. 8p+7 -- and hands lane i column i of the eight
+// rows.  The points of an odd piece sit swizzled by 8 (the load side writes them that way), so the two
+// pieces a 32-lane half reads fall into different halves of the 64 LDS banks.
+struct TrFrag8 { u32x2 v; };
+NK_D void tr_issue(TrFrag8& f, uint32_t piece, int tile, int ks, int lane) {
+    const int g4 = lane >> 4, i = lane & 15;
+    const int x = 2 * tile + (g4 & 1);
+    const int row = (16 * ks + 8 * (g4 >> 1) + (i >> 1)) ^ ((x & 1) << 3);
+    const uint32_t a0 = piece + x * 512 + row * 16 + (i & 1) * 8;
+    asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(f.v) : "v"(a0));
+}
+template <int N>
+NK_D void tr_wait(TrFrag8 (&f)[N]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i].v));
+}
+NK_D long tr_value8(const TrFrag8& f) { return __builtin_bit_cast(long, f.v); }
+// eight e4m3 bytes -> the bf16 operand of the same values (exact: e4m3 is a subset of bf16)
+NK_D bf16x8 fp8_to_bf16x8(const TrFrag8& f) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    u32x4 u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const f32x2 p = (w & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)f.v[w >> 1], true)
+                                : __builtin_amdgcn_cvt_pk_f32_fp8((int)f.v[w >> 1], false);
+        u[w] = pack_bf16(p[0], p[1]);
+    }
+    return __builtin_bit_cast(bf16x8, u);
+}
+NK_D float bf8_sum8(const TrFrag8& f) {       // sum of the eight e5m2 values
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const f32x2 p = (w & 1) ? __builtin_amdgcn_cvt_pk_f32_bf8((int)f.v[w >> 1], true)
+                                : __builtin_amdgcn_cvt_pk_f32_bf8((int)f.v[w >> 1], false);
+        s += p[0] + p[1];
+    }
+    return s;
+}
+template <int F> struct TrOperand { typedef TrFrag type; };
+template <> struct TrOperand<1> { typedef TrFrag8 type; };
 
 // A stage is one group of 32 points: A piece (MT*2 KiB) then B piece (NT*2 KiB).  Stages go
 // through a ring of NK_GEMM_RING LDS slots with three stages in flight, because one CU needs
@@ -147,8 +198,8 @@ NK_D int64_t gemm_dst_index(const GemmOut& a, int mt, int nt, int m_in_tile, int
     const int sa = mt >= a.MA0, sb = nt >= a.NB0;
     const GemmDst& d = a.dst[sa][sb];
     if (!d.enabled) return -1;
-    if (d.col_tiled && d.colmode == NK_COL_IDENT) r = nk_tile_feature(r);
-    if (d.row_tiled) m_in_tile = nk_tile_feature(m_in_tile);
+    if (d.col_tiled && d.colmode == NK_COL_IDENT) r = a.col8 ? nk_tile_feature8(r) : nk_tile_feature(r);
+    if (d.row_tiled) m_in_tile = a.row8 ? nk_tile_feature8(m_in_tile) : nk_tile_feature(m_in_tile);
     const int n = 32 * (nt - (sb ? a.NB0 : 0)) + r;         // column inside the B segment
     int dcol;
     if (d.colmode == NK_COL_IDENT) dcol = n < d.col_count ? d.col_base + n : -1;
@@ -164,15 +215,26 @@ NK_D int64_t gemm_dst_index(const GemmOut& a, int mt, int nt, int m_in_tile, int
     return d.w_off + (int64_t)(d.row_dst0 + mr) * d.ld + dcol;
 }
 
-template <int MT, int NT, int WM, int WN>
+// FA / FB: bytes per element of the A regions (dZ: 2 = bf16, 1 = e5m2) and of the B regions (saved
+// layer inputs: 2 = bf16, 1 = e4m3).  bf16 x bf16 and e5m2 x e4m3 go to the MFMA as they are read;
+// bf16 x e4m3 (NK_ACT_FP8) converts the B operand to bf16 in registers.  With both sides 8-bit a
+// stage is TWO groups (64 points), so that a stage keeps the bytes, the load count per wave and the
+// counted waits of the bf16 form.
+template <int MT, int NT, int WM, int WN, int FA, int FB>
 NK_D void gemm_body(const GemmSrc& a, float* slice, char* lds) {
+    static_assert(FA == 2 || FB == 1, "8-bit dZ comes with 8-bit activations");
     constexpr int TM = MT / WM, TN = NT / WN;       // wave tile, in 32x32 tiles
     static_assert(TM * WM == MT && TN * WN == NT && WM * WN <= 8, "wave grid must tile the output");
+    constexpr int NG = (FA == 1 && FB == 1) ? 2 : 1;            // groups of 32 points per stage
+    constexpr int a_blocks = MT * FA, b_blocks = NT * FB;       // 1-KiB blocks of one group's A / B piece
+    constexpr int a_bytes = NG * a_blocks * 1024;               // the stage's A pieces, then its B pieces
+    constexpr int stage_bytes = NG * (a_blocks + b_blocks) * 1024;
+    constexpr int blocks_per_stage = NG * (a_blocks + b_blocks);
+    constexpr int min_pieces = blocks_per_stage / 8;    // every wave issues at least this many loads per stage
+    typedef typename TrOperand<FA>::type OpA;
+    typedef typename TrOperand<FB>::type OpB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int stage_bytes = (MT + NT) * 2048;       // one group's A piece then B piece
-    constexpr int blocks_per_stage = (MT + NT) * 2;
-    constexpr int min_pieces = blocks_per_stage / 8;    // every wave issues at least this many loads per stage
     const bool active = wave < WM * WN;
     const int wm = active ? wave / WN : 0, wn = active ? wave % WN : 0;
     const int64_t s0 = (int64_t)((int)blockIdx.x - a.wg_begin) * a.stages_per_wg;
@@ -186,14 +248,20 @@ NK_D void gemm_body(const GemmSrc& a, float* slice, char* lds) {
         for (int i = 0; i < (blocks_per_stage + 7) / 8; ++i) {      // compile-time trip count: the compiler
             const int b = wave + 8 * i;                             // would drain vmcnt after a real loop
             if (b >= blocks_per_stage) break;
-            const bool isA = b < MT * 2;
-            const int pb = isA ? b : b - MT * 2;            // 1-KiB block inside the piece
-            const int t0 = isA ? a.MA0 : a.NB0;             // tiles of the piece's first segment
-            const int seg = pb >= 2 * t0;
+            const bool isA = b < NG * a_blocks;
+            const int bb = isA ? b : b - NG * a_blocks;
+            const int per_g = isA ? a_blocks : b_blocks, F = isA ? FA : FB;
+            const int g = NG == 1 ? 0 : (bb >= per_g ? 1 : 0);      // group inside the stage
+            const int pb = bb - g * per_g;                          // 1-KiB block inside the group's piece
+            const int t0 = isA ? a.MA0 : a.NB0;                     // tiles of the piece's first segment
+            const int seg = pb >= F * t0;
             const int seg_tiles = seg ? (isA ? MT : NT) - t0 : t0;
-            const char* src = (isA ? a.A[seg] : a.B[seg]) + stage * seg_tiles * 2048;
-            const int o = 2 * (pb - (seg ? 2 * t0 : 0)) + (lane >> 5), cpos = lane & 31;   // octet inside the segment
-            const int csrc = cpos ^ ((o & 3) << 2);           // swizzle on the source side
+            const char* src = (isA ? a.A[seg] : a.B[seg]) + (stage * NG + g) * seg_tiles * 1024 * F;
+            // 512-byte piece inside the segment (bf16: a feature octet, 8-bit: 16 features) and the
+            // point this lane fetches: swizzled on the source side so that the transposed reads are
+            // conflict-free (see tr_issue)
+            const int o = 2 * (pb - (seg ? F * t0 : 0)) + (lane >> 5), cpos = lane & 31;
+            const int csrc = cpos ^ (F == 2 ? ((o & 3) << 2) : ((o & 1) << 3));
             __builtin_amdgcn_global_load_lds((const NK_GLB void*)(src + (o * 32 + csrc) * 16),
                                              (NK_LDS void*)(dst + b * 1024), 16, 0, 0);
         }
@@ -220,41 +288,60 @@ NK_D void gemm_body(const GemmSrc& a, float* slice, char* lds) {
         else gemm_wait_barrier<0>();
         if (s + 3 < s1) issue(s + 3);
         if (active) {
-            const uint32_t pa = lds0 + (uint32_t)(s % NK_GEMM_RING) * stage_bytes;
-            const uint32_t pb = pa + MT * 2048;
-            TrFrag fa[2][TM], fb[2][TN];        // both k-steps of the stage: the second is read under the first's MFMAs
+            const uint32_t st0 = lds0 + (uint32_t)(s % NK_GEMM_RING) * stage_bytes;
+            // k-steps of the stage (two per group): the next one is read under this one's MFMAs
+            constexpr int NKS = 2 * NG;
+            OpA fa[2][TM];
+            OpB fb[2][TN];
+            auto read_step = [&](int kk, int slot) {
+                const uint32_t pa = st0 + (kk >> 1) * a_blocks * 1024;
+                const uint32_t pb = st0 + a_bytes + (kk >> 1) * b_blocks * 1024;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) tr_issue(fa[0][i], pa, wm * TM + i, 0, lane);
+                for (int i = 0; i < TM; ++i) tr_issue(fa[slot][i], pa, wm * TM + i, kk & 1, lane);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) tr_issue(fb[0][j], pb, wn * TN + j, 0, lane);
+                for (int j = 0; j < TN; ++j) tr_issue(fb[slot][j], pb, wn * TN + j, kk & 1, lane);
+            };
+            read_step(0, 0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                tr_wait(fa[ks]); tr_wait(fb[ks]);
-                if (ks == 0) {
+            for (int kk = 0; kk < NKS; ++kk) {
+                const int cur = kk & 1;
+                tr_wait(fa[cur]); tr_wait(fb[cur]);
+                if (kk + 1 < NKS) read_step(kk + 1, cur ^ 1);
+                const bool bias_step = want_bias && (((int)(s & 1) * NKS + kk) % WN) == wn;   // the WN waves of a row take turns
+                if constexpr (FA == 2) {
+                    bf16x8 af[TM], bf[TN];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) tr_issue(fa[1][i], pa, wm * TM + i, 1, lane);
+                    for (int i = 0; i < TM; ++i) af[i] = tr_value(fa[cur][i]);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) tr_issue(fb[1][j], pb, wn * TN + j, 1, lane);
-                }
-                bf16x8 af[TM], bf[TN];
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (FB == 2) bf[j] = tr_value(fb[cur][j]);
+                        else bf[j] = fp8_to_bf16x8(fb[cur][j]);
+                    }
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = tr_value(fa[ks][i]);
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = tr_value(fb[ks][j]);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    if (bias_step) {        // bias gradient: the sum of the A operand over the k-step's points
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                // bias gradient: the WN waves of a row share it, each takes its k-steps
-                if (want_bias && ((2 * (int)(s & 1) + ks) % WN) == wn) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            bf16x2 pr; pr[0] = af[i][2 * w]; pr[1] = af[i][2 * w + 1];
-                            bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
+                            for (int w = 0; w < 4; ++w) {
+                                bf16x2 pr; pr[0] = af[i][2 * w]; pr[1] = af[i][2 * w + 1];
+                                bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
+                            }
                         }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(tr_value8(fa[cur][i]), tr_value8(fb[cur][j]),
+                                                                                   acc[i][j], 0, 0, 0);
+                    if (bias_step) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) bsum[i] += bf8_sum8(fa[cur][i]);
                     }
                 }
             }
@@ -279,6 +366,7 @@ NK_D void gemm_body(const GemmSrc& a, float* slice, char* lds) {
     }
 }
 
+template <int FA, int FB>
 __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int prod = 0;
@@ -287,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
     const int wg = (int)blockIdx.x - a.wg_begin;
     switch (a.shape) {
 #define NK_GEMM_CASE(ID, MT, NT, WM, WN, NS) \
-    case ID: gemm_body<MT, NT, WM, WN>(a, batch.partial + a.partial_off + (int64_t)wg * gemm_slice_floats(MT, NT, WN), lds); break;
+    case ID: gemm_body<MT, NT, WM, WN, FA, FB>(a, batch.partial + a.partial_off + (int64_t)wg * gemm_slice_floats(MT, NT, WN), lds); break;
         NK_GEMM_SHAPES(NK_GEMM_CASE)
 #undef NK_GEMM_CASE
     default: break;
@@ -322,7 +410,8 @@ __global__ __launch_bounds__(256) void k_dw_reduce(ReduceBatch batch) {
             const int mt = b >> 5, r = b & 31;
             const int sa = mt >= a.MA0;
             const GemmDst& d = a.dst[sa][0];
-            const int mr = 32 * (mt - (sa ? a.MA0 : 0)) + (d.row_tiled ? nk_tile_feature(r) : r) - d.row_first;
+            const int mr = 32 * (mt - (sa ? a.MA0 : 0)) +
+                           (d.row_tiled ? (a.row8 ? nk_tile_feature8(r) : nk_tile_feature(r)) : r) - d.row_first;
             if (a.b_off[sa] >= 0 && mr >= 0 && mr < d.row_count) dst = a.b_off[sa] + d.row_dst0 + mr;
             p = p0 + (int64_t)n_rows * 64 + mt * WN * 32 + r;
             terms = WN;
@@ -344,7 +433,7 @@ __global__ __launch_bounds__(256) void k_dw_reduce(ReduceBatch batch) {
     }
     part[sg][lane] = sum;
     __syncthreads();
-    if (sg == 0 && dst >= 0) a.grad[dst] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (sg == 0 && dst >= 0) a.grad[dst] += ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) * a.scale;
 }
 
 static GemmDst gemm_dst(int w_off, int ld, int row_first, int row_count, int colmode, int col_base, int col_count,
@@ -361,6 +450,8 @@ struct GemmQueue {
     GemmSrc src[NK_GEMM_MAX_PRODUCTS];
     GemmOut out[NK_GEMM_MAX_PRODUCTS];
     int n = 0;
+    int fa = 2, fb = 2;     // bytes per element of the A (dZ) and B (layer input) regions, all products alike
+    float scale = 1.0f;     // what the reduction multiplies the sums by
 };
 
 // A0 (+A1) against B0 (+B1); widths in features (multiples of 32, 0 = segment absent)
@@ -371,7 +462,7 @@ static void queue_gemm(GemmQueue& q, const char* A0, int wA0, const char* A1, in
     GemmOut& o = q.out[q.n];
     g.A[0] = A0; g.A[1] = A1 ? A1 : A0; g.MA0 = wA0 / 32;
     g.B[0] = B0; g.B[1] = B1 ? B1 : B0; g.NB0 = wB0 / 32;
-    g.n_stages = G;
+    g.n_stages = (q.fa == 1 && q.fb == 1) ? G / 2 : G;     // all-8-bit stages hold two groups (G is a multiple of 8)
     g.partial_off = 0; g.stages_per_wg = 0; g.wg_begin = 0; g.shape = -1;     // set per launch (flush_gemms)
     g.want_bias = (b_off0 >= 0 || b_off1 >= 0) ? 1 : 0;
     o.mt = (wA0 + wA1) / 32; o.nt = (wB0 + wB1) / 32; o.wn = 0;
@@ -380,6 +471,7 @@ static void queue_gemm(GemmQueue& q, const char* A0, int wA0, const char* A1, in
         for (int j = 0; j < 2; ++j) o.dst[i][j] = dst[i][j];
     o.b_off[0] = b_off0; o.b_off[1] = b_off1;
     o.n_slices = 0; o.partial_off = 0;
+    o.row8 = q.fa == 1; o.col8 = q.fb == 1; o.scale = q.scale;
     o.grad = grad;
     ++q.n;
 }
@@ -429,7 +521,10 @@ static int flush_gemms(GemmQueue& q, float* partial, int64_t partial_bytes, hipS
         if (id == n_shapes) NK_FAIL(NK_ERR_UNSUPPORTED, "dW GEMM: no kernel for %d x %d tiles", o.mt, o.nt);
         q.src[k].shape = id;
         o.wn = shapes[id][3];
-        stage_ns[k] = shapes[id][4];
+        // stage cost of the 8-bit forms: the measured bf16 figure scaled by the stage's bytes (a stage of
+        // the all-8-bit form is two groups and moves what the bf16 stage of one group does)
+        const int blocks16 = 2 * (o.mt + o.nt), blocks = (q.fa == 1 && q.fb == 1) ? blocks16 : q.fa * o.mt + q.fb * o.nt;
+        stage_ns[k] = (int64_t)shapes[id][4] * blocks / blocks16;
         static const char* const cost_env = getenv("NK_GEMM_COSTS");      // (tuning) "id:ns,id:ns,..."
         if (cost_env) {
             for (const char* c = cost_env; c && *c; ) {
@@ -440,7 +535,7 @@ static int flush_gemms(GemmQueue& q, float* partial, int64_t partial_bytes, hipS
             }
         }
         total += q.src[k].n_stages * stage_ns[k];
-        const int need = NK_GEMM_RING * (o.mt + o.nt) * 2048;
+        const int need = NK_GEMM_RING * blocks * 1024;
         if (need > lds_bytes) lds_bytes = need;
     }
     // K-slice lengths: every workgroup gets about the same time (at least a few stages, so the
@@ -478,13 +573,16 @@ static int flush_gemms(GemmQueue& q, float* partial, int64_t partial_bytes, hipS
     batch.partial = partial;
     if (off * 4 > partial_bytes)
         NK_FAIL(NK_ERR_WORKSPACE, "dW GEMM: partial-sum scratch too small (%lld > %lld bytes)", (long long)(off * 4), (long long)partial_bytes);
-    static bool lds_allowed[NK_MAX_GPUS];
-    if (!lds_allowed[dev]) {        // the most any shape asks for: four stages of the skip layer's product
-        NK_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_gemm, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         NK_GEMM_RING * (8 + 10) * 2048));
-        lds_allowed[dev] = true;
+    const int fmt = q.fa == 2 ? (q.fb == 2 ? 0 : 1) : 2;
+    const void* kern = fmt == 0 ? (const void*)k_dw_gemm<2, 2> : fmt == 1 ? (const void*)k_dw_gemm<2, 1> : (const void*)k_dw_gemm<1, 1>;
+    static bool lds_allowed[NK_MAX_GPUS][3];
+    if (!lds_allowed[dev][fmt]) {   // the most any shape asks for: four stages of the skip layer's product
+        NK_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, NK_GEMM_RING * (8 + 10) * 2048));
+        lds_allowed[dev][fmt] = true;
     }
-    hipLaunchKernelGGL(k_dw_gemm, dim3((unsigned)wg), dim3(512), lds_bytes, stream, batch);
+    if (fmt == 0) hipLaunchKernelGGL((k_dw_gemm<2, 2>), dim3((unsigned)wg), dim3(512), lds_bytes, stream, batch);
+    else if (fmt == 1) hipLaunchKernelGGL((k_dw_gemm<2, 1>), dim3((unsigned)wg), dim3(512), lds_bytes, stream, batch);
+    else hipLaunchKernelGGL((k_dw_gemm<1, 1>), dim3((unsigned)wg), dim3(512), lds_bytes, stream, batch);
     NK_CHECK_LAUNCH("k_dw_gemm");
     for (int first = 0; first < q.n; first += NK_REDUCE_BATCH) {
         const int count = q.n - first < NK_REDUCE_BATCH ? q.n - first : NK_REDUCE_BATCH;
@@ -502,18 +600,21 @@ static int flush_gemms(GemmQueue& q, float* partial, int64_t partial_bytes, hipS
     return NK_OK;
 }
 
-static int64_t dz_region_bytes(const NkPlan& p, int64_t R, int32_t n) {
-    return (nk_dz_offset(p, nk_dz_count(p), nk_groups(R * (int64_t)n)) + 255) & ~(int64_t)255;
+static int64_t dz_region_bytes(const NkPlan& p, int64_t R, int32_t n, int deb) {
+    return (nk_dz_offset(p, nk_dz_count(p), nk_groups(R * (int64_t)n), deb) + 255) & ~(int64_t)255;
 }
 
-extern "C" int64_t nk_dz_bytes(const nk_arch* arch, int64_t R, int32_t n) {
+int64_t nk_dz_bytes_fmt(const nk_arch* arch, int64_t R, int32_t n, int act_format) {
     NkPlan p;
     int rc = nk_build_plan(arch, &p);
     if (rc < 0) return rc;
     if (R <= 0 || n <= 0) { nk_set_error("nk_dz_bytes: non-positive size"); return NK_ERR_ARG; }
+    if (act_format < NK_ACT_BF16 || act_format > NK_ACT_FP8_BF8) { nk_set_error("unknown act_format %d", act_format); return NK_ERR_ARG; }
     // dZ regions, then the partial-sum scratch of the weight-gradient launches
-    return dz_region_bytes(p, R, n) + gemm_partial_bytes(p.W);
+    return dz_region_bytes(p, R, n, nk_dz_elem_bytes(act_format)) + gemm_partial_bytes(p.W);
 }
+
+extern "C" int64_t nk_dz_bytes(const nk_arch* arch, int64_t R, int32_t n) { return nk_dz_bytes_fmt(arch, R, n, NK_ACT_BF16); }
 
 // dZ chain of one network: d_raw -> dZ of every layer (bf16, into job.dz)
 int nk_mlp_backward_chain(const NkBwdJob& j, hipStream_t st) {
@@ -528,17 +629,24 @@ int nk_mlp_backward_chain(const NkBwdJob& j, hipStream_t st) {
     a.packed_t = (const char*)j.packed + (int64_t)p.fwd_blocks * 1024;
     a.act = (const char*)j.act; a.d_raw = j.d_raw; a.dz = (char*)j.dz;
     a.P = j.R * (int64_t)j.n; a.G = nk_groups(a.P);
+    if (j.act_format < NK_ACT_BF16 || j.act_format > NK_ACT_FP8_BF8) NK_FAIL(NK_ERR_ARG, "nk_mlp_backward: unknown act_format %d", j.act_format);
+    a.act_eb = nk_act_elem_bytes(j.act_format);
+    const bool d8 = nk_dz_elem_bytes(j.act_format) == 1;
+    a.dz_scale = d8 ? j.dz_scale : 1.0f;
+    if (d8 && !(j.dz_scale > 0.0f)) NK_FAIL(NK_ERR_ARG, "nk_mlp_backward: e5m2 dZ needs a positive dz_scale");
     const int nw = nk_waves_per_wg(1);
     static const int env_stagger = []() { const char* e = getenv("NK_STAGGER_BWD"); return e ? atoi(e) : 1; }();
     a.stagger = env_stagger;
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
+#define NK_BWD_LAUNCH(W_, WD_, NW_, LDS_) do { \
+        if (d8) hipLaunchKernelGGL((k_mlp_bwd<W_, WD_, NW_, true>), grid, block, LDS_, st, a); \
+        else hipLaunchKernelGGL((k_mlp_bwd<W_, WD_, NW_, false>), grid, block, LDS_, st, a); } while (0)
     if (p.W == 256) {
-        if (nw == 8) hipLaunchKernelGGL((k_mlp_bwd<256, 128, 8>), grid, block, 3 * (16 + 1) * 1024, st, a);
-        else hipLaunchKernelGGL((k_mlp_bwd<256, 128, 4>), grid, block, 3 * (16 + 1) * 1024, st, a);
+        if (nw == 8) NK_BWD_LAUNCH(256, 128, 8, 3 * (16 + 1) * 1024); else NK_BWD_LAUNCH(256, 128, 4, 3 * (16 + 1) * 1024);
     } else {
-        if (nw == 8) hipLaunchKernelGGL((k_mlp_bwd<128, 64, 8>), grid, block, 3 * (8 + 1) * 1024, st, a);
-        else hipLaunchKernelGGL((k_mlp_bwd<128, 64, 4>), grid, block, 3 * (8 + 1) * 1024, st, a);
+        if (nw == 8) NK_BWD_LAUNCH(128, 64, 8, 3 * (8 + 1) * 1024); else NK_BWD_LAUNCH(128, 64, 4, 3 * (8 + 1) * 1024);
     }
+#undef NK_BWD_LAUNCH
     NK_CHECK_LAUNCH("k_mlp_bwd");
     return NK_OK;
 }
@@ -552,8 +660,8 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
     const int D = p.D, W = p.W, WD = p.WD;
     const int64_t G = nk_groups(j.R * (int64_t)j.n);
     float* grad = j.grad;
-    auto act = [&](int idx) { return (const char*)j.act + nk_act_offset(p, idx, G); };
-    auto dz = [&](int idx) { return (const char*)j.dz + nk_dz_offset(p, idx, G); };
+    auto act = [&](int idx) { return (const char*)j.act + nk_act_offset(p, idx, G, q.fb); };
+    auto dz = [&](int idx) { return (const char*)j.dz + nk_dz_offset(p, idx, G, q.fa); };
     const NkLayer& lrgb = p.layer[D + 3];
     const NkLayer& lviews = p.layer[D + 2];
     const NkLayer& lfeat = p.layer[D + 1];
@@ -602,6 +710,10 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
 int nk_mlp_backward_gemms(const NkBwdJob* jobs, int count, hipStream_t st) {
     if (count < 1 || count > 2) NK_FAIL(NK_ERR_ARG, "nk_mlp_backward_gemms: %d networks", count);
     GemmQueue q;
+    if (count == 2 && (jobs[0].act_format != jobs[1].act_format || jobs[0].dz_scale != jobs[1].dz_scale))
+        NK_FAIL(NK_ERR_ARG, "nk_mlp_backward_gemms: networks sharing a launch must share the saved-tensor format");
+    q.fa = nk_dz_elem_bytes(jobs[0].act_format); q.fb = nk_act_elem_bytes(jobs[0].act_format);
+    q.scale = q.fa == 1 ? 1.0f / jobs[0].dz_scale : 1.0f;
     for (int k = 0; k < count; ++k) {
         int rc = queue_network_gemms(q, jobs[k]);
         if (rc < 0) return rc;
@@ -610,13 +722,13 @@ int nk_mlp_backward_gemms(const NkBwdJob* jobs, int count, hipStream_t st) {
     NkPlan p0;
     int rc = nk_build_plan(jobs[0].arch, &p0);
     if (rc < 0) return rc;
-    float* partial = (float*)((char*)jobs[0].dz + dz_region_bytes(p0, jobs[0].R, jobs[0].n));
+    float* partial = (float*)((char*)jobs[0].dz + dz_region_bytes(p0, jobs[0].R, jobs[0].n, q.fa));
     int64_t partial_bytes = gemm_partial_bytes(p0.W);
     if (count > 1) {        // products of both networks share launches: slices sized for the wider one
         NkPlan p1;
         if ((rc = nk_build_plan(jobs[1].arch, &p1)) < 0) return rc;
         if (p1.W > p0.W) {
-            partial = (float*)((char*)jobs[1].dz + dz_region_bytes(p1, jobs[1].R, jobs[1].n));
+            partial = (float*)((char*)jobs[1].dz + dz_region_bytes(p1, jobs[1].R, jobs[1].n, q.fa));
             partial_bytes = gemm_partial_bytes(p1.W);
         }
     }
@@ -626,6 +738,7 @@ int nk_mlp_backward_gemms(const NkBwdJob* jobs, int count, hipStream_t st) {
         for (int first = 0; first < q.n; ++first) {
             if (done[first]) continue;
             GemmQueue sub;
+            sub.fa = q.fa; sub.fb = q.fb; sub.scale = q.scale;
             for (int k = first; k < q.n; ++k)
                 if (!done[k] && q.out[k].mt == q.out[first].mt && q.out[k].nt == q.out[first].nt) {
                     sub.src[sub.n] = q.src[k]; sub.out[sub.n] = q.out[k]; ++sub.n; done[k] = true;
@@ -639,7 +752,7 @@ int nk_mlp_backward_gemms(const NkBwdJob* jobs, int count, hipStream_t st) {
 
 extern "C" int nk_mlp_backward(const nk_arch* arch, const void* packed, const void* act_save, const float* d_raw,
                                int64_t R, int32_t n, void* dz_scratch, float* grad, void* stream) {
-    const NkBwdJob j = {arch, packed, act_save, d_raw, R, n, dz_scratch, grad};
+    const NkBwdJob j = {arch, packed, act_save, d_raw, R, n, dz_scratch, grad, NK_ACT_BF16, 1.0f};
     int rc = nk_mlp_backward_chain(j, nk_stream(stream));
     if (rc < 0) return rc;
     return nk_mlp_backward_gemms(&j, 1, nk_stream(stream));

@@ -127,6 +127,8 @@ struct FwdArgs {
     char* act;             // saved activations or null
     int64_t P, G;
     int n;                 // samples per ray
+    const int32_t* live;   // inference only: compacted list of the groups to evaluate, or null (all of them)
+    const int32_t* n_live; // its length, in device memory
     int stagger;           // upper half of each workgroup's waves run the staggered stage order
 #ifdef NK_STAMPS
     long long* stamps;     // debug build: per-wave cycle stamps of one workgroup
@@ -136,25 +138,33 @@ struct FwdArgs {
 #include "nk_fwd_chain.inc"
 
 
-extern "C" int64_t nk_act_bytes(const nk_arch* arch, int64_t R, int32_t n) {
+int64_t nk_act_bytes_fmt(const nk_arch* arch, int64_t R, int32_t n, int act_format) {
     NkPlan p;
     int rc = nk_build_plan(arch, &p);
     if (rc < 0) return rc;
     if (R <= 0 || n <= 0) { nk_set_error("nk_act_bytes: non-positive size"); return NK_ERR_ARG; }
-    return nk_mask_offset(p, nk_mask_count(p), nk_groups(R * (int64_t)n));
+    if (act_format < NK_ACT_BF16 || act_format > NK_ACT_FP8_BF8) { nk_set_error("unknown act_format %d", act_format); return NK_ERR_ARG; }
+    return nk_mask_offset(p, nk_mask_count(p), nk_groups(R * (int64_t)n), nk_act_elem_bytes(act_format));
 }
 
-extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const float* ray_batch, const float* z,
-                              int64_t R, int32_t n, float* raw, void* act_save, void* stream) {
+extern "C" int64_t nk_act_bytes(const nk_arch* arch, int64_t R, int32_t n) { return nk_act_bytes_fmt(arch, R, n, NK_ACT_BF16); }
+
+// live_groups / n_live (device, inference only): evaluate only the listed groups of 32 points
+int nk_mlp_forward_fmt(const nk_arch* arch, const void* packed, const float* ray_batch, const float* z, int64_t R,
+                       int32_t n, float* raw, void* act_save, int act_format, const int32_t* live_groups,
+                       const int32_t* n_live, void* stream) {
     if (!packed || !ray_batch || !z || !raw || R <= 0 || n <= 0)
         NK_FAIL(NK_ERR_ARG, "nk_mlp_forward: null pointer or non-positive size");
     if (((uintptr_t)packed & 15) || ((uintptr_t)raw & 15) || ((uintptr_t)act_save & 15))
         NK_FAIL(NK_ERR_ARG, "nk_mlp_forward: packed, raw and act_save must be 16-byte aligned");
+    if (act_format < NK_ACT_BF16 || act_format > NK_ACT_FP8_BF8) NK_FAIL(NK_ERR_ARG, "nk_mlp_forward: unknown act_format %d", act_format);
+    if (live_groups && (act_save || !n_live)) NK_FAIL(NK_ERR_ARG, "nk_mlp_forward: a group list is for inference and needs its length");
     FwdArgs a;
     int rc = nk_build_plan(arch, &a.plan);
     if (rc < 0) return rc;
     a.packed = (const char*)packed; a.rays = ray_batch; a.z = z; a.raw = raw; a.act = (char*)act_save;
     a.P = R * (int64_t)n; a.G = nk_groups(a.P); a.n = n;
+    a.live = live_groups; a.n_live = n_live;
 #ifdef NK_STAMPS
     { const char* e = getenv("NK_STAMP_PTR"); a.stamps = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
@@ -162,10 +172,11 @@ extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const flo
     static const int env_stagger = []() { const char* e = getenv("NK_STAGGER_FWD"); return e ? atoi(e) : 0; }();
     a.stagger = env_stagger;
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
-    const bool save = act_save != nullptr;
+    const int fmt = !act_save ? 0 : (act_format == NK_ACT_BF16 ? 1 : 2);
 #define NK_FWD_LAUNCH(W_, WD_, NW_, LDS_) do { \
-        if (save) hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, true>), grid, block, LDS_, nk_stream(stream), a); \
-        else hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, false>), grid, block, LDS_, nk_stream(stream), a); } while (0)
+        if (fmt == 1) hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, 1>), grid, block, LDS_, nk_stream(stream), a); \
+        else if (fmt == 2) hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, 2>), grid, block, LDS_, nk_stream(stream), a); \
+        else hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, 0>), grid, block, LDS_, nk_stream(stream), a); } while (0)
     if (a.plan.W == 256) {
         constexpr int lds_bytes = 3 * (16 + 4 + 1) * 1024;     // three ring slots
         if (nw == 8) NK_FWD_LAUNCH(256, 128, 8, lds_bytes); else NK_FWD_LAUNCH(256, 128, 4, lds_bytes);
@@ -176,4 +187,9 @@ extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const flo
 #undef NK_FWD_LAUNCH
     NK_CHECK_LAUNCH("k_mlp_fwd");
     return NK_OK;
+}
+
+extern "C" int nk_mlp_forward(const nk_arch* arch, const void* packed, const float* ray_batch, const float* z,
+                              int64_t R, int32_t n, float* raw, void* act_save, void* stream) {
+    return nk_mlp_forward_fmt(arch, packed, ray_batch, z, R, n, raw, act_save, NK_ACT_BF16, nullptr, nullptr, stream);
 }

@@ -33,7 +33,7 @@ int nk_waves_per_wg(int backward) {
 }
 
 extern "C" const char* nk_last_error(void) { return g_err; }
-extern "C" int nk_version(void) { return 100; }
+extern "C" int nk_version(void) { return 101; }
 
 int nk_build_plan(const nk_arch* a, NkPlan* p) {
     if (!a || !p) NK_FAIL(NK_ERR_ARG, "nk_build_plan: null argument");

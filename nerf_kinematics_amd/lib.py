@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerfkin.so")
+# NK_LIB (development only): another build of the library, e.g. to compare two builds bit by bit
+LIB_PATH = os.environ.get("NK_LIB") or os.path.join(_HERE, "libnerfkin.so")
 
 NK_LINEAGE_RUN_NERF = 0
 NK_LINEAGE_FLEXIBLE = 1
@@ -17,6 +18,9 @@ NK_LINEAGE_FLEXIBLE = 1
 # nk_render_rays_bwd runs the weight-gradient products of both networks in one shared launch up to
 # this many fine-network points per call (NK_PAIR_GEMM_MAX_POINTS in csrc/nk_api.cpp)
 PAIR_GEMM_MAX_POINTS = 1 << 20
+
+# nk_render_opts.act_format: formats of the tensors saved for backward (experiments beyond bf16)
+ACT_FORMATS = {"bf16": 0, "fp8": 1, "fp8bf8": 2}
 
 STREAM_STRATIFIED, STREAM_PDF, STREAM_NOISE_COARSE, STREAM_NOISE_FINE, STREAM_PIXELS = 0, 1, 2, 3, 4
 
@@ -35,8 +39,8 @@ class NkStepState(C.Structure):
 class NkRenderOpts(C.Structure):
     _fields_ = [("num_coarse", C.c_int32), ("num_fine", C.c_int32), ("perturb", C.c_int32),
                 ("lindisp", C.c_int32), ("white_background", C.c_int32),
-                ("radiance_field_noise_std", C.c_float), ("seed", C.c_uint32), ("reserved", C.c_int32),
-                ("state", C.c_void_p)]
+                ("radiance_field_noise_std", C.c_float), ("seed", C.c_uint32), ("act_format", C.c_int32),
+                ("state", C.c_void_p), ("skip_empty_eps", C.c_float), ("reserved", C.c_int32)]
 
 
 class NkCamera(C.Structure):

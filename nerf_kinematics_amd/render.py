@@ -9,6 +9,7 @@ memory.  Bad shapes / dtypes raise ``ValueError`` before any launch.
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -38,11 +39,22 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def make_opts(num_coarse: int, num_fine: int, perturb: bool = False, lindisp: bool = False,
               radiance_field_noise_std: float = 0.0, white_background: bool = False,
-              seed: int = 0) -> _lib.NkRenderOpts:
+              seed: int = 0, act_format: str = "bf16", skip_empty_eps: float = 0.0) -> _lib.NkRenderOpts:
     if num_coarse < 2 or num_fine < 0:
         raise ValueError(f"num_coarse={num_coarse} (>= 2) / num_fine={num_fine} (>= 0)")
+    if act_format not in _lib.ACT_FORMATS:
+        raise ValueError(f"act_format={act_format!r}: expected one of {sorted(_lib.ACT_FORMATS)}")
+    if not (skip_empty_eps >= 0.0):
+        raise ValueError(f"skip_empty_eps={skip_empty_eps} (>= 0)")
     return _lib.NkRenderOpts(int(num_coarse), int(num_fine), int(bool(perturb)), int(bool(lindisp)),
-                             int(bool(white_background)), float(radiance_field_noise_std), int(seed) & 0xFFFFFFFF)
+                             int(bool(white_background)), float(radiance_field_noise_std), int(seed) & 0xFFFFFFFF,
+                             _lib.ACT_FORMATS[act_format], None, float(skip_empty_eps), 0)
+
+
+def dz_scale(R: int) -> float:
+    """The power of two ``nk_render_rays_bwd`` multiplies dZ by before rounding it to e5m2 under
+    ``act_format="fp8bf8"`` (and divides out of the weight gradient again): 2^(ceil(log2 R) + 6)."""
+    return 2.0 ** (math.ceil(math.log2(R)) + 6)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -236,18 +248,23 @@ class _RenderRays(torch.autograd.Function):
 def render_rays(ray_batch: torch.Tensor, coarse: NeRFModel, fine: Optional[NeRFModel] = None, *,
                 num_coarse: int = 64, num_fine: int = 128, perturb: bool = False, lindisp: bool = False,
                 radiance_field_noise_std: float = 0.0, white_background: bool = False, seed: int = 0,
-                training: Optional[bool] = None):
+                training: Optional[bool] = None, act_format: str = "bf16", skip_empty_eps: float = 0.0):
     """Volume-render rays: returns ``(rgb_fine, disp_fine, acc_fine, rgb_coarse, disp_coarse, acc_coarse)``.
 
     With ``num_fine == 0`` the fine slots repeat the coarse maps.  Differentiable w.r.t.
     ``coarse.flat`` and ``fine.flat`` (through the rgb maps) when they require grad.
+
+    Two experiments beyond the reference's behaviour, both off by default: ``act_format`` ("fp8",
+    "fp8bf8") saves the tensors backward needs in 8-bit formats (training calls), and
+    ``skip_empty_eps`` > 0 skips the fine network where the coarse pass found nothing (inference calls).
     """
     rb = _f32(ray_batch, "ray_batch", (None, 11))
     if num_fine > 0 and fine is None:
         raise ValueError("render_rays: num_fine > 0 needs a fine model")
     if num_fine == 0:
         fine = None
-    opts = make_opts(num_coarse, num_fine, perturb, lindisp, radiance_field_noise_std, white_background, seed)
+    opts = make_opts(num_coarse, num_fine, perturb, lindisp, radiance_field_noise_std, white_background, seed,
+                     act_format=act_format, skip_empty_eps=skip_empty_eps)
     if training is None:
         training = torch.is_grad_enabled() and (coarse.flat.requires_grad or (fine is not None and fine.flat.requires_grad))
     flat_f = fine.flat if fine is not None else None

@@ -39,6 +39,9 @@ class TrainOpts:
     betas: tuple = (0.9, 0.999)
     eps: float = 1e-8
     seed: int = 42
+    # format of the tensors saved for backward (experiment, no counterpart in the reference):
+    # "bf16" (default), "fp8" = e4m3 activations, "fp8bf8" = e4m3 activations and e5m2 dZ
+    act_format: str = "bf16"
 
     @staticmethod
     def from_config(cfg: dict) -> "TrainOpts":
@@ -50,7 +53,8 @@ class TrainOpts:
                          radiance_field_noise_std=float(t.get("radiance_field_noise_std", 0.0)),
                          white_background=bool(t.get("white_background", False)), lr=float(o.get("lr", 5e-4)),
                          lr_decay=int(s.get("lr_decay", 250)), lr_decay_factor=float(s.get("lr_decay_factor", 0.1)),
-                         seed=int(cfg.get("experiment", {}).get("randomseed", 42)))
+                         seed=int(cfg.get("experiment", {}).get("randomseed", 42)),
+                         act_format=str(t.get("act_format", "bf16")))
 
 
 def lr_at(iteration: int, o: TrainOpts) -> float:
@@ -95,6 +99,9 @@ class Trainer:
         # backward call and ONE all-reduce of the flat buffer is the default data-parallel step.
         self.overlap_allreduce: bool = os.environ.get("NK_OVERLAP_ALLREDUCE", "0") == "1"
         self.force_collective = False       # tests: issue the collectives on a one-rank group too
+        # measurement hook: when a list, every step appends its [(begin, end), ...] event pairs recorded
+        # on the compute stream around the gradient collective(s)
+        self.comm_events: Optional[list] = None
         self.iteration = 0          # training iterations done (drives the learning-rate decay and the RNG)
         self.opt_steps = 0          # optimiser steps done (Adam bias correction; survives resume)
         self._alloc(self.R)
@@ -103,7 +110,7 @@ class Trainer:
     def _alloc(self, R: int) -> None:
         o = self.opts
         self.ropts = make_opts(o.num_coarse, o.num_fine if self.fine is not None else 0, o.perturb, o.lindisp,
-                               o.radiance_field_noise_std, o.white_background, o.seed)
+                               o.radiance_field_noise_std, o.white_background, o.seed, act_format=o.act_format)
         fc = self.fine._c if self.fine is not None else None
         self.ws_bytes = _lib.check(self.L.nk_render_workspace_bytes(self.coarse._c, fc, self.ropts, R, 1))
         self.ws = None              # allocated on the first non-staged step
@@ -146,6 +153,14 @@ class Trainer:
             bwd = lambda d_f, d_c: _lib.check(L.nk_render_rays_bwd(
                 self.coarse._c, self.coarse.packed.data_ptr(), fc, fp, ray_batch.data_ptr(), R, self.ropts, self.ws_ptr,
                 self.ws_bytes, d_f, d_c, gc.data_ptr(), _ptr(gf), st))
+            timed = []
+
+            def mark():
+                if self.comm_events is None:
+                    return None
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                return e
             if self._split_allreduce(R):
                 # the fine network's gradient is complete before the coarse backward starts: its half
                 # of the flat buffer is reduced while the coarse chain and products run
@@ -153,13 +168,19 @@ class Trainer:
                 bwd(_ptr(self.d_rgb_f), None)
                 h_f = nkdist.allreduce_sum_start(self.grad[self._nc_pad:], self.pg, self.force_collective)
                 bwd(None, self.d_rgb_c.data_ptr())
+                b = mark()          # what the step still waits for once the coarse backward is queued
                 h_c = nkdist.allreduce_sum_start(self.grad[:self._nc_pad], self.pg, self.force_collective)
                 nkdist.allreduce_wait(h_f); nkdist.allreduce_wait(h_c)
+                timed.append((b, mark()))
             else:
                 bwd(_ptr(self.d_rgb_f), self.d_rgb_c.data_ptr())
                 if self.world > 1:
                     from . import dist as nkdist
+                    b = mark()
                     nkdist.allreduce_sum_(self.grad, self.pg)       # one flat buffer, both networks
+                    timed.append((b, mark()))
+            if self.comm_events is not None:
+                self.comm_events.append(timed)
             self.iteration += 1
             self.opt_steps += 1
             _lib.check(L.nk_adam_step(self.params.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
@@ -281,7 +302,7 @@ class GraphedStep:
         self.state_dev = torch.zeros(C.sizeof(_lib.NkStepState), dtype=torch.uint8, device=dev)
         o = trainer.ropts
         self.ropts = _lib.NkRenderOpts(o.num_coarse, o.num_fine, o.perturb, o.lindisp, o.white_background,
-                                       o.radiance_field_noise_std, 0, 0, self.state_dev.data_ptr())
+                                       o.radiance_field_noise_std, 0, o.act_format, self.state_dev.data_ptr(), 0.0, 0)
         if trainer.ws is None:
             trainer.ws = torch.empty(trainer.ws_bytes + 256, dtype=torch.uint8, device=dev)
             trainer.ws_ptr = (trainer.ws.data_ptr() + 255) & ~255

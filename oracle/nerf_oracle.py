@@ -262,28 +262,68 @@ class _RoundGradBf16(torch.autograd.Function):
         return g.to(torch.bfloat16).to(g.dtype)
 
 
+def _e4m3r(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def _e5m2r(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.float8_e5m2).to(torch.float32)
+
+
+class _LinearSaved8(torch.autograd.Function):
+    """Linear layer of the bf16-emulating network whose WEIGHT-GRADIENT product sees 8-bit copies of
+    its operands, as the HIP path's experimental saved-tensor formats do (no counterpart in the
+    reference): the layer input rounded once from fp32 to OCP e4m3 ("fp8", "fp8bf8") and dL/d(output)
+    scaled by a power of two, rounded once from fp32 to OCP e5m2 and scaled back ("fp8bf8").  The
+    forward product and the gradient passed on to the layer below use bf16 operands as before."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act_format, dz_scale):
+        wb = w.to(torch.bfloat16).to(torch.float32)
+        ctx.save_for_backward(x, wb)
+        ctx.act_format, ctx.dz_scale = act_format, dz_scale
+        return x.to(torch.bfloat16).to(torch.float32) @ wb.t() + b
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wb = ctx.saved_tensors
+        g16 = g.to(torch.bfloat16).to(torch.float32)
+        gz = _e5m2r(g * ctx.dz_scale) / ctx.dz_scale if ctx.act_format == "fp8bf8" else g16
+        lead = x.shape[:-1].numel()
+        gz2, x2 = gz.reshape(lead, -1), _e4m3r(x).reshape(lead, -1)
+        return g16 @ wb, gz2.t() @ x2, gz2.sum(0), None, None
+
+
 class NeRFNet:
     """MLP evaluated from a dict of named tensors (``name.weight`` / ``name.bias``).
 
     ``emulate_bf16``: round weights and every layer input to bf16 (fp32 accumulate, fp32 bias) and,
     in backward, every dL/d(pre-activation); this is where the HIP MFMA path rounds, so tests can
-    use a tight tolerance.
+    use a tight tolerance.  ``act_format`` ("fp8", "fp8bf8", with ``dz_scale``) additionally rounds
+    the operands of the weight-gradient products as the HIP path's 8-bit saved-tensor formats do.
     """
 
-    def __init__(self, arch: Arch, params: Dict[str, torch.Tensor], emulate_bf16: bool = False):
+    def __init__(self, arch: Arch, params: Dict[str, torch.Tensor], emulate_bf16: bool = False,
+                 act_format: str = "bf16", dz_scale: float = 1.0):
         self.arch = arch
         self.p = params
         self.emu = emulate_bf16
+        if act_format not in ("bf16", "fp8", "fp8bf8"):
+            raise ValueError(f"act_format={act_format!r}")
+        if act_format != "bf16" and not emulate_bf16:
+            raise ValueError("the 8-bit saved-tensor formats are emulated on top of emulate_bf16")
+        self.act_format, self.dz_scale = act_format, float(dz_scale)
 
     # -- flat <-> named ---------------------------------------------------------------------
     @staticmethod
-    def from_flat(arch: Arch, flat: torch.Tensor, emulate_bf16: bool = False) -> "NeRFNet":
+    def from_flat(arch: Arch, flat: torch.Tensor, emulate_bf16: bool = False, act_format: str = "bf16",
+                  dz_scale: float = 1.0) -> "NeRFNet":
         p, off = {}, 0
         for name, (o, i) in arch.param_shapes():
             p[name + ".weight"] = flat[off:off + o * i].view(o, i); off += o * i
             p[name + ".bias"] = flat[off:off + o]; off += o
         assert off == flat.numel(), (off, flat.numel())
-        return NeRFNet(arch, p, emulate_bf16)
+        return NeRFNet(arch, p, emulate_bf16, act_format, dz_scale)
 
     @staticmethod
     def flatten_state_dict(arch: Arch, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -308,6 +348,8 @@ class NeRFNet:
     # -- forward ----------------------------------------------------------------------------
     def _lin(self, name: str, x: torch.Tensor) -> torch.Tensor:
         w, b = self.p[name + ".weight"], self.p[name + ".bias"]
+        if self.emu and self.act_format != "bf16":
+            return _LinearSaved8.apply(x, w, b, self.act_format, self.dz_scale)
         if self.emu:
             w, x = _bf16r(w), _bf16r(x)
             return _RoundGradBf16.apply(x @ w.t() + b)

@@ -1,0 +1,189 @@
+"""GPU parity tests of the experimental 8-bit saved-tensor formats (nk_render_opts.act_format).
+
+"fp8" saves every layer input as OCP e4m3 (rounded once from fp32), "fp8bf8" additionally saves dZ as
+OCP e5m2 scaled by a power of two.  Both only change the operands of the weight-gradient products:
+the forward outputs and the gradient chain stay on bf16 operands.  The oracle's emulation rounds at
+the same places (oracle/nerf_oracle.py `_LinearSaved8`).  Tolerances (relative L2 per parameter
+tensor, half of it for the whole gradient): "fp8" 5e-2, the bound of the bf16 gradient tests; "fp8bf8"
+1e-1 -- e5m2 keeps two mantissa bits, so wherever the HIP chain's fp32 dZ and the oracle's differ in
+the last bits and straddle a rounding boundary the stored values differ by 12-25 %, which shows in
+the first layer's weights (end of the chain, smallest gradient: 0.066 measured) and nowhere else
+(whole gradient: 0.002).  The distance to the bf16 gradient is printed beside it.
+Off by default: every other test in this suite runs the bf16 format.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+from test_gpu_backward import check_grads, oarch, per_tensor_rel_err, rays, report_grads
+
+pytestmark = pytest.mark.gpu
+
+FORMATS = ("fp8", "fp8bf8")
+TOL = {"fp8": 5e-2, "fp8bf8": 1e-1}
+
+
+@pytest.fixture(scope="module")
+def nk():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU and the HIP library; there is no CPU fallback")
+    import nerf_kinematics_amd as nk
+    nk.load()
+    return nk
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def oracle_grads(arch_c, arch_f, fc, ff, rb, target, kw, fmt, R_scale, chunk=1024):
+    """Gradient of the NeRF loss through the oracle emulating saved-tensor format `fmt`, evaluated
+    in pieces of `chunk` rays."""
+    from nerf_kinematics_amd.render import dz_scale
+    fco, ffo = fc.clone().requires_grad_(True), ff.clone().requires_grad_(True)
+    R, total = rb.shape[0], 0.0
+    s_dz = dz_scale(R_scale)
+    for s in range(0, R, chunk):
+        co = O.NeRFNet.from_flat(oarch(arch_c), fco, True, fmt, s_dz)
+        fo = O.NeRFNet.from_flat(oarch(arch_f), ffo, True, fmt, s_dz)
+        out = O.render_rays(rb[s:s + chunk], co, fo, O.RenderOpts(64, 128, **kw), ray_offset=s)
+        t = target[s:s + chunk]
+        part = (((out["rgb_coarse"] - t) ** 2).sum() + ((out["rgb_fine"] - t) ** 2).sum()) / (3 * R)
+        part.backward()
+        total += float(part.detach())
+    return total, fco.grad, ffo.grad
+
+
+def hip_grads(nk, dev, arch_c, arch_f, fc, ff, rb, target, kw, fmt):
+    c, f = nk.NeRFModel(arch_c, fc.to(dev).clone()), nk.NeRFModel(arch_f, ff.to(dev).clone())
+    c.flat.requires_grad_(True); f.flat.requires_grad_(True)
+    out = nk.render_rays(rb.to(dev), c, f, num_coarse=64, num_fine=128, act_format=fmt, **kw)
+    tg = target.to(dev)
+    loss = ((out[3] - tg) ** 2).mean() + ((out[0] - tg) ** 2).mean()
+    loss.backward()
+    return float(loss.detach()), c.flat.grad.detach().clone(), f.flat.grad.detach().clone(), [o.detach().clone() for o in out]
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+@pytest.mark.parametrize("which", ["flexible", "run_nerf", "mixed"])
+def test_render_rays_gradients_8bit(nk, dev, which, fmt):
+    """Both network shapes (and a 4x128 coarse under an 8x256 fine network: one weight-gradient
+    launch with products of both widths) at a small batch, jitter and noise on."""
+    arch_f = nk.ARCH_LEGO_CKPT if which == "flexible" else nk.ARCH_RUN_NERF
+    arch_c = nk.ARCH_RUN_NERF if which == "run_nerf" else nk.ARCH_LEGO_CKPT
+    R = 48 if which == "flexible" else 24
+    fc, ff = O.NeRFNet.init_flat(oarch(arch_c), 1), O.NeRFNet.init_flat(oarch(arch_f), 2)
+    rb, g = rays(R, 21)
+    target = torch.rand(R, 3, generator=g)
+    kw = dict(perturb=True, radiance_field_noise_std=0.2, seed=5)
+    loss, gc, gf, out = hip_grads(nk, dev, arch_c, arch_f, fc, ff, rb, target, kw, fmt)
+    loss16, gc16, gf16, out16 = hip_grads(nk, dev, arch_c, arch_f, fc, ff, rb, target, kw, "bf16")
+    # the formats only touch what backward reads: every forward output is bit-identical to bf16's
+    for a, b in zip(out, out16):
+        assert torch.equal(a, b)
+    assert loss == loss16
+    lref, gc_ref, gf_ref = oracle_grads(arch_c, arch_f, fc, ff, rb, target, kw, fmt, R, chunk=R)
+    assert abs(loss - lref) < 2e-3 * lref + 1e-5
+    for tag, arch, got, ref, g16 in (("coarse", arch_c, gc, gc_ref, gc16), ("fine", arch_f, gf, gf_ref, gf16)):
+        report_grads(f"{which} {fmt} {tag} vs the oracle emulating {fmt}", arch, got, ref)
+        print(f"    distance to the HIP bf16 gradient: {float((got - g16).norm() / g16.norm()):.4f}")
+        check_grads(arch, got, ref, tol=TOL[fmt])
+        assert float((got - g16).norm() / g16.norm()) < 0.15        # an 8-bit copy is not a different gradient
+
+
+@pytest.fixture(scope="module")
+def big_batch(nk, dev):
+    """8x256 pair after 300 iterations, 5 507 rays x (64 + 128) samples = 1 057 344 fine points: above
+    the shared-launch limit (one weight-gradient launch per network, ~256 K-slices each) and ragged."""
+    from nerf_kinematics_amd.datasets import RaySampler, teacher_scene
+    from nerf_kinematics_amd.trainer import Trainer, TrainOpts
+    arch = nk.ARCH_RUN_NERF
+    R = 5507
+    scene = teacher_scene(None, 8, 0, 100, dev)
+    opts = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=1024, perturb=True, radiance_field_noise_std=0.2,
+                     lr=5e-4, seed=42)
+    tr = Trainer(arch, arch, opts, dev)
+    smp = RaySampler(scene, 1024, seed=3)
+    for i in range(300):
+        tr.step(*smp.next(i))
+    rb, target = RaySampler(scene, R, seed=8).next(300)
+    return dict(arch=arch, R=R, rb=rb.clone(), target=target.clone(), fc=tr.coarse.flat.detach().clone(),
+                ff=tr.fine.flat.detach().clone(), kw=dict(perturb=True, radiance_field_noise_std=0.2, seed=1234))
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_large_batch_gradients_8bit(nk, dev, big_batch, fmt):
+    """The launch regime the benchmark runs (more than 2^20 fine points per call)."""
+    b = big_batch
+    arch = b["arch"]
+    loss, gc, gf, _ = hip_grads(nk, dev, arch, arch, b["fc"], b["ff"], b["rb"], b["target"], b["kw"], fmt)
+    lref, gc_ref, gf_ref = oracle_grads(arch, arch, b["fc"].cpu(), b["ff"].cpu(), b["rb"].cpu(), b["target"].cpu(), b["kw"],
+                                        fmt, b["R"])
+    print(f"loss: HIP {loss:.6f}, oracle {lref:.6f}")
+    assert abs(loss - lref) < 2e-3 * lref + 1e-5
+    report_grads(f"8x256 coarse, 5507 rays, {fmt}", arch, gc, gc_ref)
+    report_grads(f"8x256 fine,   5507 rays, {fmt}", arch, gf, gf_ref)
+    check_grads(arch, gc, gc_ref, tol=TOL[fmt])
+    check_grads(arch, gf, gf_ref, tol=TOL[fmt])
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_8bit_gradient_is_bit_reproducible_and_formats_do_not_leak(nk, dev, fmt):
+    """Two calls give the same bits, and a bf16 call after an 8-bit one gives bf16's bits (the
+    format is an argument of the call, not state of the library)."""
+    arch = nk.ARCH_RUN_NERF
+    fc, ff = O.NeRFNet.init_flat(oarch(arch), 1), O.NeRFNet.init_flat(oarch(arch), 2)
+    rb, g = rays(200, 3)
+    target = torch.rand(200, 3, generator=g)
+    kw = dict(perturb=True, radiance_field_noise_std=0.2, seed=9)
+    ref16 = hip_grads(nk, dev, arch, arch, fc, ff, rb, target, kw, "bf16")
+    a = hip_grads(nk, dev, arch, arch, fc, ff, rb, target, kw, fmt)
+    b = hip_grads(nk, dev, arch, arch, fc, ff, rb, target, kw, fmt)
+    again16 = hip_grads(nk, dev, arch, arch, fc, ff, rb, target, kw, "bf16")
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(ref16[1], again16[1]) and torch.equal(ref16[2], again16[2])
+    assert not torch.equal(a[2], ref16[2])
+
+
+def test_8bit_formats_train_like_bf16(nk, dev):
+    """400 iterations of the 4x128 pair on a small synthetic scene per format, same seeds: held-out
+    PSNR of the 8-bit runs within 1 dB of the bf16 run (trajectories of a chaotic optimisation; the
+    multi-seed comparison lives under profiles/)."""
+    from nerf_kinematics_amd.datasets import RaySampler, teacher_scene
+    from nerf_kinematics_amd.metrics import mse2psnr
+    from nerf_kinematics_amd.trainer import Trainer, TrainOpts
+    arch = nk.ARCH_LEGO_CKPT
+    scene = teacher_scene(None, 12, 3, 48, dev, num_coarse=64, num_fine=64)
+    res = {}
+    for fmt in ("bf16",) + FORMATS:
+        opts = TrainOpts(num_coarse=32, num_fine=32, num_random_rays=1024, perturb=True, radiance_field_noise_std=0.2,
+                         lr=5e-3, seed=42, act_format=fmt)
+        tr = Trainer(arch, arch, opts, dev)
+        smp = RaySampler(scene, 1024, seed=42)
+        for i in range(400):
+            tr.step(*smp.next(i))
+        vals = []
+        for k in scene.i_val:
+            out = tr.render(scene.rays(int(k), dev))
+            vals.append(mse2psnr(float(((out["rgb_fine"] - scene.target(int(k))) ** 2).mean())))
+        res[fmt] = sum(vals) / len(vals)
+    print("held-out PSNR after 400 iterations:", {k: round(v, 2) for k, v in res.items()})
+    assert res["bf16"] > 17.0
+    for fmt in FORMATS:
+        assert abs(res[fmt] - res["bf16"]) < 1.0, res
+
+
+def test_unknown_format_is_rejected(nk, dev):
+    arch = nk.ARCH_LEGO_CKPT
+    with pytest.raises(ValueError):
+        nk.make_opts(64, 128, act_format="fp4")
+    from nerf_kinematics_amd import lib as nklib
+    L = nk.load()
+    o = nk.make_opts(64, 128)
+    o.act_format = 7
+    c = nk.NeRFModel(arch, O.NeRFNet.init_flat(oarch(arch), 1).to(dev))
+    with pytest.raises(ValueError):
+        nklib.check(L.nk_render_workspace_bytes(c._c, c._c, o, 64, 1))
