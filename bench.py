@@ -26,6 +26,7 @@ Extra objects on the JSON line:
                 view (bytes read / duration) sits beside it under "hbm", and "per_kernel" holds the
                 same two views of the three heavy launches (forward chain, backward chain, dW)
   value_long    the same step timed over >= 200 further steps (the driver's --steps 20 is 0.4 s)
+  value_8bit_formats  the same step with the experimental 8-bit saved-tensor formats (never `value`), N == 1
   value_r1024   the same step at the reference's own batch size (num_random_rays: 1024), N == 1
   render_400x400_ms  whole-image inference (nerf.validation settings), one 400x400 view, N == 1
   heldout_psnr  PSNR on held-out views after a short fixed-seed training run, N == 1
@@ -406,12 +407,34 @@ def main():
             tr.render(rb)
         torch.cuda.synchronize()
         t_img = (time.perf_counter() - t0) / 5
+        tr.render(rb, opts={"skip_empty_eps": 1e-3})
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tr.render(rb, opts={"skip_empty_eps": 1e-3})
+        torch.cuda.synchronize()
+        t_skip = (time.perf_counter() - t0) / 5
         res["render_400x400_ms"] = {"value": t_img * 1e3, "unit": "ms", "rays": int(rb.shape[0]), "repeats": 5,
+                                    "with_skip_empty_eps_1e-3_ms": t_skip * 1e3,
                                     "rays_per_s": rb.shape[0] / t_img,
                                     "mfma_frac": rb.shape[0] * 256 * FLOP_PER_EVAL_8x256 / t_img / 1e12 / PEAK_BF16_TFLOPS,
                                     "note": "Trainer.render: 64+128 samples, no jitter, no noise, nothing saved"}
         tr = None
         torch.cuda.empty_cache()
+        if a.act_format == "bf16":
+            # the same step with the experimental 8-bit saved-tensor formats (off by default; never `value`)
+            res["value_8bit_formats"] = {}
+            for fmt in ("fp8", "fp8bf8"):
+                o8 = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=rays, perturb=True,
+                               radiance_field_noise_std=0.2, lr=5e-4, seed=42, act_format=fmt)
+                tr8 = Trainer(nk.ARCH_RUN_NERF, nk.ARCH_RUN_NERF, o8, dev, rays_per_step=rays)
+                t8 = timed_steps(tr8, RaySampler(scene, rays, seed=1234), 40, 5)
+                res["value_8bit_formats"][fmt] = {"value": rays * 192 / t8, "unit": "ray-samples/s", "ms_per_step": t8 * 1e3,
+                                                  "steps": 40, "warmup": 5}
+                tr8 = None
+                torch.cuda.empty_cache()
+            res["value_8bit_formats"]["note"] = ("nk_render_opts.act_format: fp8 = layer inputs saved as e4m3, fp8bf8 = and dZ as "
+                                                 "e5m2; forward outputs unchanged, weight gradient coarser (tests/test_gpu_fp8.py)")
         opts1k = TrainOpts(num_coarse=64, num_fine=128, num_random_rays=1024, perturb=True,
                            radiance_field_noise_std=0.2, lr=5e-4, seed=42, act_format=a.act_format)
         tr1k = Trainer(nk.ARCH_RUN_NERF, nk.ARCH_RUN_NERF, opts1k, dev, rays_per_step=1024)

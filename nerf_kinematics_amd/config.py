@@ -22,6 +22,10 @@ _RENDER_DEFAULT = {
     "chunksize": 131072, "lindisp": False, "num_coarse": 64, "num_fine": 64, "perturb": False,
     "radiance_field_noise_std": 0.0, "white_background": False,
 }
+# Two keys the reference's files do not have, both experiments that are off unless a file names them:
+#   nerf.train.act_format            "bf16" | "fp8" | "fp8bf8": format of the tensors saved for backward
+#   nerf.validation.skip_empty_eps   > 0: renders skip the fine network where the coarse pass saw nothing
+ACT_FORMATS = ("bf16", "fp8", "fp8bf8")
 DEFAULTS: Dict[str, Any] = {
     "dataset": {"type": "blender", "basedir": "cache/nerf_synthetic/lego", "cachedir": None, "near": 2, "far": 6,
                 "half_res": True, "no_ndc": True, "testskip": 1, "downsample_factor": 8, "llffhold": 8},
@@ -77,6 +81,10 @@ def validate(cfg: dict) -> dict:
             raise ConfigError(f"models.{which}.num_encoding_fn_xyz: 1..10, got {m['num_encoding_fn_xyz']}")
         if not 1 <= int(m["num_encoding_fn_dir"]) <= 4:
             raise ConfigError(f"models.{which}.num_encoding_fn_dir: 1..4, got {m['num_encoding_fn_dir']}")
+    if nerf["train"].get("act_format", "bf16") not in ACT_FORMATS:
+        raise ConfigError(f"nerf.train.act_format: one of {ACT_FORMATS}, got {nerf['train']['act_format']!r}")
+    if not float(nerf["validation"].get("skip_empty_eps", 0.0)) >= 0.0:
+        raise ConfigError(f"nerf.validation.skip_empty_eps: >= 0, got {nerf['validation']['skip_empty_eps']!r}")
     for block in ("train", "validation"):
         r = nerf[block]
         if int(r["num_coarse"]) < 2:
@@ -114,6 +122,9 @@ def render_kwargs(cfg: dict, block: str) -> dict:
     """``nerf.train`` / ``nerf.validation`` -> keyword arguments of ``render_rays``."""
     r = cfg["nerf"][block]
     fine = int(r["num_fine"]) if cfg["models"].get("fine") is not None else 0
-    return dict(num_coarse=int(r["num_coarse"]), num_fine=fine, perturb=bool(r["perturb"]),
-                lindisp=bool(r["lindisp"]), radiance_field_noise_std=float(r["radiance_field_noise_std"]),
-                white_background=bool(r["white_background"]))
+    kw = dict(num_coarse=int(r["num_coarse"]), num_fine=fine, perturb=bool(r["perturb"]),
+              lindisp=bool(r["lindisp"]), radiance_field_noise_std=float(r["radiance_field_noise_std"]),
+              white_background=bool(r["white_background"]))
+    if block == "validation" and float(r.get("skip_empty_eps", 0.0)) > 0.0:
+        kw["skip_empty_eps"] = float(r["skip_empty_eps"])
+    return kw

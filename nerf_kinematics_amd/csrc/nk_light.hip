@@ -511,13 +511,16 @@ extern "C" int nk_sample_pdf(const float* z_coarse, const float* weights, int64_
 // One thread per fine sample, 32 consecutive samples = one group of the fine network's launch.  A
 // sample is "near something" when one of the four coarse samples around its depth (two on either
 // side) has compositing weight >= eps; a group with no such sample gets zero rows in raw_f and is
-// left out of the list.  The list is filled through a counter, so its order varies from run to run;
-// the rendered values do not depend on it (every listed group is evaluated on its own).
-__global__ __launch_bounds__(256) void k_mark_live_groups(const float* __restrict__ zc, const float* __restrict__ wc,
-                                                          const float* __restrict__ z_all, int64_t P, int Nc, int N, float eps,
-                                                          int32_t* __restrict__ live, int32_t* __restrict__ n_live,
-                                                          float* __restrict__ raw_f) {
-    const int64_t pt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// left out of the list.  The list is filled through a counter (one update per block of 32 groups), so
+// the order of its blocks varies from run to run; the rendered values do not depend on it (every
+// listed group is evaluated on its own).
+__global__ __launch_bounds__(1024) void k_mark_live_groups(const float* __restrict__ zc, const float* __restrict__ wc,
+                                                           const float* __restrict__ z_all, int64_t P, int Nc, int N, float eps,
+                                                           int32_t* __restrict__ live, int32_t* __restrict__ n_live,
+                                                           float* __restrict__ raw_f) {
+    __shared__ int flag[32];        // the block's 32 groups
+    __shared__ int base;
+    const int64_t pt = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     bool near = false;
     if (pt < P) {
         const int64_t ray = pt / N;
@@ -531,10 +534,24 @@ __global__ __launch_bounds__(256) void k_mark_live_groups(const float* __restric
             if (k >= 0 && k < Nc && w[k] >= eps) near = true;
     }
     const uint64_t vote = __ballot(near);
-    const int half = (threadIdx.x >> 5) & 1;
-    const bool group_live = ((vote >> (32 * half)) & 0xFFFFFFFFull) != 0;
+    const int g = threadIdx.x >> 5;                     // group inside the block
+    const bool group_live = ((vote >> (32 * (g & 1))) & 0xFFFFFFFFull) != 0;
+    if ((threadIdx.x & 31) == 0) flag[g] = group_live ? 1 : 0;
+    __syncthreads();
+    // one counter update per block (a counter update per group was 1.3 ms per 65 536 rays: they all
+    // hit one address); the block's live groups take consecutive slots in ascending order
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int k = 0; k < 32; ++k) n += flag[k];
+        base = n ? atomicAdd(n_live, n) : 0;
+    }
+    __syncthreads();
     if (group_live) {
-        if ((threadIdx.x & 31) == 0) live[atomicAdd(n_live, 1)] = (int32_t)(pt >> 5);
+        if ((threadIdx.x & 31) == 0) {
+            int before = 0;
+            for (int k = 0; k < g; ++k) before += flag[k];
+            live[base + before] = (int32_t)(pt >> 5);
+        }
     } else if (pt < P) {
         *(float4*)(raw_f + pt * 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
@@ -546,7 +563,7 @@ int nk_mark_live_groups(const float* z_coarse, const float* w_coarse, const floa
         NK_FAIL(NK_ERR_ARG, "nk_mark_live_groups: null pointer or bad size");
     const int64_t P = R * (int64_t)N;
     NK_CHECK_HIP(hipMemsetAsync(n_live, 0, 4, nk_stream(stream)));
-    hipLaunchKernelGGL(k_mark_live_groups, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, nk_stream(stream), z_coarse,
+    hipLaunchKernelGGL(k_mark_live_groups, dim3((unsigned)((P + 1023) / 1024)), dim3(1024), 0, nk_stream(stream), z_coarse,
                        w_coarse, z_all, P, (int)Nc, (int)N, eps, live, n_live, raw_f);
     NK_CHECK_LAUNCH("k_mark_live_groups");
     return NK_OK;

@@ -153,7 +153,10 @@ template <> struct TrOperand<1> { typedef TrFrag8 type; };
 // ~50 KB of loads outstanding at all times to keep its share of HBM bandwidth busy.  Order per
 // stage s: counted wait (stage s landed; the loads of s+1, s+2 stay in flight) -> barrier (also
 // retires every wave's reads of slot (s-1) % RING) -> issue stage s+3 into that slot -> MFMAs.
-enum { NK_GEMM_RING = 4 };
+// (The bf16 x e4m3 form, whose stages are a quarter fewer bytes, was also run with a ring of five and
+// four stages in flight: 12 % slower per stage, so every form keeps the ring of four.)
+enum { NK_GEMM_RING = 4, NK_GEMM_RING_MIXED = 4 };
+NK_HD int gemm_ring(int fa, int fb) { return (fa == 2 && fb == 1) ? NK_GEMM_RING_MIXED : NK_GEMM_RING; }
 
 template <int N>
 NK_D void gemm_wait_barrier() {
@@ -176,19 +179,22 @@ enum { NK_GEMM_MAX_PRODUCTS = 24, NK_REDUCE_BATCH = 12 };
 struct GemmBatch { GemmSrc g[NK_GEMM_MAX_PRODUCTS]; float* partial; int count; };
 struct ReduceBatch { GemmOut g[NK_REDUCE_BATCH]; const float* partial; };
 
-// (A tiles, B tiles, waves down, waves across, ns per stage) of every product the supported
-// networks produce.  The last column is what the K-slices of a launch are balanced with: the
-// measured time of one stage (32 points) when every CU runs that shape (NK_GEMM_PER_SHAPE=1
-// launches the shapes one by one; NK_GEMM_COSTS="id:ns,..." overrides entries).  The thinnest
-// product (1 x 2 tiles, 6 KB per stage) is latency-bound and slows down next to bandwidth-bound
-// neighbours: it is entered a third above its stand-alone 713 ns.
+// (A tiles, B tiles, waves down, waves across, ns per stage in the bf16 / bf16 x e4m3 / e5m2 x e4m3
+// form) of every product the supported networks produce.  The last columns are what the K-slices of
+// a launch are balanced with: the measured time of one stage (32 points; 64 in the all-8-bit form)
+// when every CU runs that shape (NK_GEMM_PER_SHAPE=1 launches the shapes one by one,
+// tools/gemm_costs.py turns the kernel trace into this column; NK_GEMM_COSTS="id:ns,..." overrides
+// entries).  The thinnest product (1 x 2 tiles, 6 KB per stage) is latency-bound and slows down next
+// to bandwidth-bound neighbours: it is entered a third above its stand-alone 713 ns.  The 8-bit
+// columns of the width-128 shapes are the bf16 figure times the ratio measured on the width-256 shape
+// of the same layer.
 //   width 256: trunk, trunk 0, rgb, feature + alpha, skip (h + gamma(x)), views (feat + gamma(d))
 //   width 128: the same six
 #define NK_GEMM_SHAPES(X) \
-    X(0, 8, 8, 2, 4, 1455) X(1, 8, 2, 4, 2, 921) X(2, 1, 4, 1, 4, 571) X(3, 9, 8, 1, 8, 1589) \
-    X(4, 8, 10, 4, 2, 1669) X(5, 4, 9, 2, 3, 1148) \
-    X(6, 4, 4, 2, 4, 694) X(7, 4, 2, 4, 2, 601) X(8, 1, 2, 1, 2, 950) X(9, 5, 4, 1, 4, 831) \
-    X(10, 4, 6, 2, 2, 900) X(11, 2, 5, 2, 1, 673)
+    X(0, 8, 8, 2, 4, 1455, 1397, 1833) X(1, 8, 2, 4, 2, 921, 820, 976) X(2, 1, 4, 1, 4, 571, 474, 634) \
+    X(3, 9, 8, 1, 8, 1589, 1510, 2082) X(4, 8, 10, 4, 2, 1669, 1519, 2070) X(5, 4, 9, 2, 3, 1148, 1079, 1469) \
+    X(6, 4, 4, 2, 4, 694, 666, 874) X(7, 4, 2, 4, 2, 601, 535, 637) X(8, 1, 2, 1, 2, 950, 789, 1055) \
+    X(9, 5, 4, 1, 4, 831, 789, 1089) X(10, 4, 6, 2, 2, 900, 819, 1116) X(11, 2, 5, 2, 1, 673, 633, 861)
 
 NK_HD int64_t gemm_slice_floats(int MT, int NT, int WN) { return (int64_t)MT * NT * 1024 + (int64_t)MT * WN * 32; }
 
@@ -231,6 +237,7 @@ NK_D void gemm_body(const GemmSrc& a, float* slice, char* lds) {
     constexpr int stage_bytes = NG * (a_blocks + b_blocks) * 1024;
     constexpr int blocks_per_stage = NG * (a_blocks + b_blocks);
     constexpr int min_pieces = blocks_per_stage / 8;    // every wave issues at least this many loads per stage
+    constexpr int RING = (FA == 2 && FB == 1) ? NK_GEMM_RING_MIXED : NK_GEMM_RING;
     typedef typename TrOperand<FA>::type OpA;
     typedef typename TrOperand<FB>::type OpB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -243,7 +250,7 @@ NK_D void gemm_body(const GemmSrc& a, float* slice, char* lds) {
     if (s0 >= s1) return;
 
     auto issue = [&](int64_t stage) {
-        char* dst = lds + (int)(stage % NK_GEMM_RING) * stage_bytes;
+        char* dst = lds + (int)(stage % RING) * stage_bytes;
 #pragma unroll
         for (int i = 0; i < (blocks_per_stage + 7) / 8; ++i) {      // compile-time trip count: the compiler
             const int b = wave + 8 * i;                             // would drain vmcnt after a real loop
@@ -279,16 +286,21 @@ NK_D void gemm_body(const GemmSrc& a, float* slice, char* lds) {
     const bool want_bias = a.want_bias != 0;
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)(NK_LDS char*)lds;
-    for (int64_t s = s0; s < s0 + 3 && s < s1; ++s) issue(s);
+    for (int64_t s = s0; s < s0 + RING - 1 && s < s1; ++s) issue(s);
     for (int64_t s = s0; s < s1; ++s) {
-        // loads issued after stage s: those of the stages s+1, s+2 that exist
+        // loads issued after stage s: those of the stages s+1 .. s+RING-2 that exist
         const int64_t left = s1 - 1 - s;
-        if (left >= 2) gemm_wait_barrier<2 * min_pieces>();
-        else if (left == 1) gemm_wait_barrier<min_pieces>();
+        // (fewer blocks than waves -- thin products in the 8-bit formats: a wave issues one load per
+        // stage or none at all; counting one keeps the loads of the later stages in flight, and a wave
+        // without loads has nothing outstanding, so any count lets it through)
+        constexpr int mp = min_pieces > 0 ? min_pieces : 1;
+        if (RING > 4 && left >= 3) gemm_wait_barrier<3 * mp>();
+        else if (left >= 2) gemm_wait_barrier<2 * mp>();
+        else if (left == 1) gemm_wait_barrier<mp>();
         else gemm_wait_barrier<0>();
-        if (s + 3 < s1) issue(s + 3);
+        if (s + RING - 1 < s1) issue(s + RING - 1);
         if (active) {
-            const uint32_t st0 = lds0 + (uint32_t)(s % NK_GEMM_RING) * stage_bytes;
+            const uint32_t st0 = lds0 + (uint32_t)(s % RING) * stage_bytes;
             // k-steps of the stage (two per group): the next one is read under this one's MFMAs
             constexpr int NKS = 2 * NG;
             OpA fa[2][TM];
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void k_dw_gemm(GemmBatch batch) {
     const GemmSrc& a = batch.g[prod];
     const int wg = (int)blockIdx.x - a.wg_begin;
     switch (a.shape) {
-#define NK_GEMM_CASE(ID, MT, NT, WM, WN, NS) \
+#define NK_GEMM_CASE(ID, MT, NT, WM, WN, NS, NSM, NS8) \
     case ID: gemm_body<MT, NT, WM, WN, FA, FB>(a, batch.partial + a.partial_off + (int64_t)wg * gemm_slice_floats(MT, NT, WN), lds); break;
         NK_GEMM_SHAPES(NK_GEMM_CASE)
 #undef NK_GEMM_CASE
@@ -502,8 +514,8 @@ static int64_t gemm_partial_bytes(int W) {
 }
 
 static int flush_gemms(GemmQueue& q, float* partial, int64_t partial_bytes, hipStream_t stream) {
-    static const int shapes[][5] = {
-#define NK_GEMM_ROW(ID, MT, NT, WM, WN, NS) {MT, NT, WM, WN, NS},
+    static const int shapes[][7] = {
+#define NK_GEMM_ROW(ID, MT, NT, WM, WN, NS, NSM, NS8) {MT, NT, WM, WN, NS, NSM, NS8},
         NK_GEMM_SHAPES(NK_GEMM_ROW)
 #undef NK_GEMM_ROW
     };
@@ -521,10 +533,9 @@ static int flush_gemms(GemmQueue& q, float* partial, int64_t partial_bytes, hipS
         if (id == n_shapes) NK_FAIL(NK_ERR_UNSUPPORTED, "dW GEMM: no kernel for %d x %d tiles", o.mt, o.nt);
         q.src[k].shape = id;
         o.wn = shapes[id][3];
-        // stage cost of the 8-bit forms: the measured bf16 figure scaled by the stage's bytes (a stage of
-        // the all-8-bit form is two groups and moves what the bf16 stage of one group does)
-        const int blocks16 = 2 * (o.mt + o.nt), blocks = (q.fa == 1 && q.fb == 1) ? blocks16 : q.fa * o.mt + q.fb * o.nt;
-        stage_ns[k] = (int64_t)shapes[id][4] * blocks / blocks16;
+        // 1-KiB blocks of a stage (a stage of the all-8-bit form is two groups)
+        const int blocks = (q.fa == 1 && q.fb == 1) ? 2 * (o.mt + o.nt) : q.fa * o.mt + q.fb * o.nt;
+        stage_ns[k] = shapes[id][q.fa == 2 ? (q.fb == 2 ? 4 : 5) : 6];
         static const char* const cost_env = getenv("NK_GEMM_COSTS");      // (tuning) "id:ns,id:ns,..."
         if (cost_env) {
             for (const char* c = cost_env; c && *c; ) {
@@ -535,7 +546,7 @@ static int flush_gemms(GemmQueue& q, float* partial, int64_t partial_bytes, hipS
             }
         }
         total += q.src[k].n_stages * stage_ns[k];
-        const int need = NK_GEMM_RING * blocks * 1024;
+        const int need = gemm_ring(q.fa, q.fb) * blocks * 1024;
         if (need > lds_bytes) lds_bytes = need;
     }
     // K-slice lengths: every workgroup gets about the same time (at least a few stages, so the
@@ -577,7 +588,8 @@ static int flush_gemms(GemmQueue& q, float* partial, int64_t partial_bytes, hipS
     const void* kern = fmt == 0 ? (const void*)k_dw_gemm<2, 2> : fmt == 1 ? (const void*)k_dw_gemm<2, 1> : (const void*)k_dw_gemm<1, 1>;
     static bool lds_allowed[NK_MAX_GPUS][3];
     if (!lds_allowed[dev][fmt]) {   // the most any shape asks for: four stages of the skip layer's product
-        NK_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, NK_GEMM_RING * (8 + 10) * 2048));
+        NK_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         fmt == 1 ? NK_GEMM_RING_MIXED * (2 * 8 + 10) * 1024 : NK_GEMM_RING * (8 + 10) * 2048));
         lds_allowed[dev][fmt] = true;
     }
     if (fmt == 0) hipLaunchKernelGGL((k_dw_gemm<2, 2>), dim3((unsigned)wg), dim3(512), lds_bytes, stream, batch);

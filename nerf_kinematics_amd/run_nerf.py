@@ -44,6 +44,12 @@ def parse_args(argv=None):
     ap.add_argument("--rays", type=int, default=None, help="override nerf.train.num_random_rays (per GPU)")
     ap.add_argument("--logdir", default=None, help="override experiment.logdir")
     ap.add_argument("--device", default=None, help="cuda:N (default: LOCAL_RANK)")
+    ap.add_argument("--act-format", choices=config_mod.ACT_FORMATS, default=None,
+                    help="override nerf.train.act_format: format of the tensors saved for backward "
+                         "(bf16 = default; fp8 / fp8bf8 = experimental 8-bit formats)")
+    ap.add_argument("--skip-empty-eps", type=float, default=None,
+                    help="override nerf.validation.skip_empty_eps: renders skip the fine network where every "
+                         "nearby coarse weight is below this value (0 = off, the default; experiment)")
     ap.add_argument("--graph", action="store_true",
                     help="single GPU: replay the training iteration as one HIP graph (same results bit for bit)")
     return ap.parse_args(argv)
@@ -116,6 +122,10 @@ def main(argv=None) -> int:
         over.setdefault("experiment", {})["train_iters"] = a.iters
     if a.rays is not None:
         over.setdefault("nerf", {}).setdefault("train", {})["num_random_rays"] = a.rays
+    if a.act_format is not None:
+        over.setdefault("nerf", {}).setdefault("train", {})["act_format"] = a.act_format
+    if a.skip_empty_eps is not None:
+        over.setdefault("nerf", {}).setdefault("validation", {})["skip_empty_eps"] = a.skip_empty_eps
     cfg = config_mod.load_config(a.config, over)
 
     rank, world, local = nkdist.init_from_env()

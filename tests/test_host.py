@@ -50,6 +50,8 @@ def test_stored_learning_rate_is_reproduced(golden_dir):
     (lambda c: c["optimizer"].__setitem__("type", "SGD"), "optimizer.type"),
     (lambda c: c["dataset"].__setitem__("type", "llff"), "dataset.type"),
     (lambda c: c["nerf"]["train"].__setitem__("num_coarse", 1), "num_coarse"),
+    (lambda c: c["nerf"]["train"].__setitem__("act_format", "fp4"), "act_format"),
+    (lambda c: c["nerf"]["validation"].__setitem__("skip_empty_eps", -1.0), "skip_empty_eps"),
 ])
 def test_unsupported_config_is_named(golden_dir, tmp_path, edit, key):
     import yaml
@@ -60,6 +62,19 @@ def test_unsupported_config_is_named(golden_dir, tmp_path, edit, key):
     p.write_text(yaml.safe_dump(raw))
     with pytest.raises(ValueError, match=key.split(".")[-1]):
         config_mod.load_config(str(p))
+
+
+def test_experiment_keys_default_off_and_reach_the_render_options(golden_dir):
+    """The two keys the reference's files do not have: absent -> bf16 saved tensors and no skipping
+    (render_kwargs then carries nothing the reference's render_rays does not take)."""
+    cfg = config_mod.load_config(os.path.join(golden_dir, "lego-lowres3_config.yml"))
+    assert TrainOpts.from_config(cfg).act_format == "bf16"
+    assert "skip_empty_eps" not in config_mod.render_kwargs(cfg, "validation")
+    cfg = config_mod.load_config(os.path.join(golden_dir, "lego-lowres3_config.yml"),
+                                 {"nerf": {"train": {"act_format": "fp8bf8"}, "validation": {"skip_empty_eps": 1e-3}}})
+    assert TrainOpts.from_config(cfg).act_format == "fp8bf8"
+    assert config_mod.render_kwargs(cfg, "validation")["skip_empty_eps"] == 1e-3
+    assert "skip_empty_eps" not in config_mod.render_kwargs(cfg, "train")
 
 
 def test_config_round_trip(golden_dir, tmp_path):
