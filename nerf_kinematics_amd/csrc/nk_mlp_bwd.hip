@@ -145,6 +145,45 @@ NK_D float bf8_sum8(const TrFrag8& f) {       // sum of the eight e5m2 values
     }
     return s;
 }
+// Operand of the K = 64 form (v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales: twice the 8-bit
+// rate of the K = 16 form): 32 bytes per lane, feature = lane & 31, the 32 points of lane-half
+// lane >> 5.  Which point sits in which byte does not matter as long as A and B agree -- the product
+// sums over all of them -- so lane-half h simply takes the stage's group h, eight points per
+// transposed read.  piece = LDS address of group 0's piece, group_bytes = distance to group 1's.
+struct TrFrag64 { u32x2 v[4]; };
+NK_D void tr_issue64(TrFrag64& f, uint32_t piece, int group_bytes, int tile, int lane) {
+    const int g4 = lane >> 4, i = lane & 15;
+    const int x = 2 * tile + (g4 & 1), sw = (x & 1) << 3;
+    const uint32_t base = piece + (g4 >> 1) * group_bytes + x * 512 + (i & 1) * 8;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t a0 = base + ((8 * r + (i >> 1)) ^ sw) * 16;
+        asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(f.v[r]) : "v"(a0));
+    }
+}
+NK_D void tr_landed(TrFrag64& f) {      // after the wait that covers its reads
+    asm volatile("" : "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2]), "+v"(f.v[3]));
+}
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+NK_D i32x8 tr_value64(const TrFrag64& f) {
+    return i32x8{(int)f.v[0][0], (int)f.v[0][1], (int)f.v[1][0], (int)f.v[1][1], (int)f.v[2][0], (int)f.v[2][1], (int)f.v[3][0], (int)f.v[3][1]};
+}
+// s_waitcnt lgkmcnt(min(n, 15)) for an n known after unrolling (LDS reads return in order)
+NK_D void lgkm_wait_upto(int n) {
+    switch (n < 15 ? n : 15) {
+#define NK_LGKM_CASE(N) case N: asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); break;
+        NK_LGKM_CASE(0) NK_LGKM_CASE(1) NK_LGKM_CASE(2) NK_LGKM_CASE(3) NK_LGKM_CASE(4) NK_LGKM_CASE(5) NK_LGKM_CASE(6) NK_LGKM_CASE(7)
+        NK_LGKM_CASE(8) NK_LGKM_CASE(9) NK_LGKM_CASE(10) NK_LGKM_CASE(11) NK_LGKM_CASE(12) NK_LGKM_CASE(13) NK_LGKM_CASE(14)
+#undef NK_LGKM_CASE
+    default: asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); break;
+    }
+}
+// Measured on the 16 384-ray step (e5m2 x e4m3 products of an 8x256 network): 2.74 ms per launch
+// against 2.51 ms for the K = 16 form -- same results, but the first MFMA of a stage waits for
+// twelve reads instead of six and the stage has no second k-step to read under; stays off.
+#ifndef NK_GEMM8_K64
+#define NK_GEMM8_K64 0
+#endif
 template <int F> struct TrOperand { typedef TrFrag type; };
 template <> struct TrOperand<1> { typedef TrFrag8 type; };
 
@@ -299,7 +338,72 @@ NK_D void gemm_body(const GemmSrc& a, float* slice, char* lds) {
         else if (left == 1) gemm_wait_barrier<mp>();
         else gemm_wait_barrier<0>();
         if (s + RING - 1 < s1) issue(s + RING - 1);
-        if (active) {
+        if constexpr (FA == 1 && FB == 1 && NK_GEMM8_K64 && TM <= 6) {     // (nine accumulator tiles + 32-byte operands spill)
+            // all-8-bit form: ONE K = 64 MFMA per tile pair and stage.  Reads: the B tiles, then the A
+            // tiles; the MFMAs of A tile i start as soon as its reads have landed (counted lgkmcnt).
+            if (active) {
+                const uint32_t st0 = lds0 + (uint32_t)(s % RING) * stage_bytes;
+                // The tiles of the longer side of the wave tile go through a ring of at most four
+                // operands in flight, the other side's stay resident for the stage.
+                const bool bias_step = want_bias && ((int)(s % WN)) == wn;      // the WN waves of a row take turns
+                auto mma = [&](int i, int j, const i32x8& av, const i32x8& bv) {
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 1 /* A: e5m2 */, 0 /* B: e4m3 */,
+                                                                                0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                };
+                auto bias_of = [&](int i, const TrFrag64& f) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { TrFrag8 t; t.v = f.v[r]; bsum[i] += bf8_sum8(t); }
+                };
+                if constexpr (TM >= TN) {
+                    constexpr int NR = TM < 4 ? TM : 4;
+                    TrFrag64 fb[TN], fa[NR];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) tr_issue64(fb[j], st0 + a_bytes, b_blocks * 1024, wn * TN + j, lane);
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) tr_issue64(fa[i], st0, a_blocks * 1024, wm * TM + i, lane);
+                    i32x8 bv[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        lgkm_wait_upto(4 * ((i + NR < TM ? i + NR : TM) - 1 - i));      // reads issued after tile i's
+                        if (i == 0) {
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) { tr_landed(fb[j]); bv[j] = tr_value64(fb[j]); }
+                        }
+                        tr_landed(fa[i % NR]);
+                        const i32x8 av = tr_value64(fa[i % NR]);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) mma(i, j, av, bv[j]);
+                        if (bias_step) bias_of(i, fa[i % NR]);
+                        if (i + NR < TM) tr_issue64(fa[i % NR], st0, a_blocks * 1024, wm * TM + i + NR, lane);
+                    }
+                } else {
+                    constexpr int NR = TN < 4 ? TN : 4;
+                    TrFrag64 fa[TM], fb[NR];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) tr_issue64(fa[i], st0, a_blocks * 1024, wm * TM + i, lane);
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) tr_issue64(fb[j], st0 + a_bytes, b_blocks * 1024, wn * TN + j, lane);
+                    i32x8 av[TM];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        lgkm_wait_upto(4 * ((j + NR < TN ? j + NR : TN) - 1 - j));
+                        if (j == 0) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) {
+                                tr_landed(fa[i]);
+                                if (bias_step) bias_of(i, fa[i]);
+                                av[i] = tr_value64(fa[i]);
+                            }
+                        }
+                        tr_landed(fb[j % NR]);
+                        const i32x8 bv = tr_value64(fb[j % NR]);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) mma(i, j, av[i], bv);
+                        if (j + NR < TN) tr_issue64(fb[j % NR], st0 + a_bytes, b_blocks * 1024, wn * TN + j + NR, lane);
+                    }
+                }
+            }
+        } else if (active) {
             const uint32_t st0 = lds0 + (uint32_t)(s % RING) * stage_bytes;
             // k-steps of the stage (two per group): the next one is read under this one's MFMAs
             constexpr int NKS = 2 * NG;

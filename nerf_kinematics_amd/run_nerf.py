@@ -174,6 +174,8 @@ def main(argv=None) -> int:
         from .trainer import GraphedStep
         graphed = GraphedStep(tr, sampler)
     log = open(os.path.join(logdir, "log.jsonl"), "a") if rank == 0 else None
+    if world > 1:
+        tr.comm_events = []         # events around the gradient all-reduce until the first report
     iters = int(exp["train_iters"])
     t_last, it_last = time.perf_counter(), tr.iteration
     loss_val = float("nan")
@@ -195,6 +197,24 @@ def main(argv=None) -> int:
                    "ray_samples_per_s": rate * (opts.num_coarse + opts.num_fine)}
             log.write(json.dumps({"train": rec}) + "\n"); log.flush()
             print(f"[TRAIN] Iter: {i} Loss: {loss_val:.6f} PSNR: {rec['psnr']:.3f} rays/s: {rate:.0f}", flush=True)
+            if tr.comm_events and len(tr.comm_events) > 1:      # once: where a multi-rank step's time goes (the loss read above has synchronised)
+                ar = [sum(b.elapsed_time(e) for b, e in pairs) for pairs in tr.comm_events[1:]] or [0.0]
+                try:
+                    ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception:        # noqa: BLE001
+                    ver = "unknown"
+                comm = {"world": world, "backend": torch.distributed.get_backend(), "rccl": ver,
+                        "allreduce_ms": sum(ar) / len(ar), "steps": len(ar), "gradient_bytes": int(tr.grad.numel()) * 4,
+                        "split_allreduce": bool(tr._split_allreduce(tr.R)),
+                        "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO")}
+                log.write(json.dumps({"comm": comm}) + "\n"); log.flush()
+                print(f"[COMM] {json.dumps(comm)}", flush=True)
+                tr.comm_events = None
+        if tr.comm_events is not None and len(tr.comm_events) > 256:
+            if rank == 0:
+                del tr.comm_events[256:]        # keep the first steps until the next report
+            else:
+                tr.comm_events = None           # only rank 0 reports
         if len(scene.i_val) and ((i % int(exp["validate_every"]) == 0 and i > 0) or last):
             k = int(scene.i_val[(i // max(int(exp["validate_every"]), 1)) % len(scene.i_val)])
             mse, psnr, p8, img = validate(tr, scene, cfg, k)        # all ranks: the render is sharded by rows

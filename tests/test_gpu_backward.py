@@ -302,8 +302,10 @@ def test_other_workgroup_sizes_in_a_child_process(nk):
     assert n >= 9, r.stdout[-500:]        # 3 + 2 backward cases, 4 forward cases
 
 
-def test_gradient_distance_to_the_fp32_oracle(nk, dev):
-    """What bf16 MFMA operands cost the gradient, as numbers: the headline shape (8x256 coarse +
+@pytest.mark.parametrize("fmt", ["bf16", "fp8", "fp8bf8"])
+def test_gradient_distance_to_the_fp32_oracle(nk, dev, fmt):
+    """What bf16 MFMA operands (and, for "fp8" / "fp8bf8", the experimental 8-bit saved-tensor
+    formats on top of them) cost the gradient, as numbers: the headline shape (8x256 coarse +
     fine, 64 + 128 samples, jitter and noise on) after 300 training iterations on the lego-teacher
     scene, HIP gradient of the NeRF loss on one batch against the gradient of the FP32 oracle (no
     bf16 emulation anywhere) at the same parameters, rays, colours and seed.  Reported per
@@ -325,15 +327,15 @@ def test_gradient_distance_to_the_fp32_oracle(nk, dev):
     kw = dict(perturb=True, radiance_field_noise_std=0.2, seed=77)
     c, f = nk.NeRFModel(arch, fc.clone()), nk.NeRFModel(arch, ff.clone())
     c.flat.requires_grad_(True); f.flat.requires_grad_(True)
-    out = nk.render_rays(rb, c, f, num_coarse=64, num_fine=128, **kw)
+    out = nk.render_rays(rb, c, f, num_coarse=64, num_fine=128, act_format=fmt, **kw)
     loss = ((out[3] - target) ** 2).mean() + ((out[0] - target) ** 2).mean()
     loss.backward()
     fco, ffo = fc.cpu().clone().requires_grad_(True), ff.cpu().clone().requires_grad_(True)
     co, fo = O.NeRFNet.from_flat(oarch(arch), fco), O.NeRFNet.from_flat(oarch(arch), ffo)
     lref = O.nerf_loss(O.render_rays(rb.cpu(), co, fo, O.RenderOpts(64, 128, **kw)), target.cpu())
     lref.backward()
-    print(f"loss: HIP {float(loss.detach()):.6f}, fp32 oracle {float(lref.detach()):.6f}")
-    assert abs(float(loss) - float(lref)) < 2e-2 * float(lref)
+    print(f"saved-tensor format {fmt} -- loss: HIP {float(loss.detach()):.6f}, fp32 oracle {float(lref.detach()):.6f}")
+    assert abs(float(loss.detach()) - float(lref.detach())) < 2e-2 * float(lref.detach())
     for name, got, ref in (("coarse", c.flat.grad.cpu(), fco.grad), ("fine", f.flat.grad.cpu(), ffo.grad)):
         tot = float(ref.norm())
         rel = float((got - ref).norm()) / tot

@@ -197,6 +197,15 @@ def test_bench_two_ranks_share_one_gpu():
     assert rec["value"] > 0 and abs(rec["value"] - 2 * 1024 * 192 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
     assert rec["roofline"]["bound"] == "mfma" and 0 < rec["roofline"]["frac"] < 1
     assert "cpu_baseline" not in rec and "heldout_psnr" not in rec          # single-GPU legs only
+    # where a multi-rank step's time went: collective time, every rank's own step time, the library and its settings
+    comm = rec["comm"]
+    assert comm["backend"] == "gloo" and comm["collectives_per_step"] == 1 and comm["split_allreduce"] is False
+    assert len(comm["ms_per_step_per_rank"]) == 2 and len(comm["allreduce_ms_per_rank"]) == 2
+    assert 0 < comm["allreduce_ms"] < rec["ms_per_step"]
+    assert comm["ms_per_step_min"] <= comm["ms_per_step_max"] <= rec["ms_per_step"] * 1.05
+    assert comm["gradient_bytes"] >= 4 * 2 * 595844
+    assert set(("NCCL_ALGO", "NCCL_PROTO")) <= set(comm["env"])
+    assert rec["roofline"]["per_kernel"]["k_dw_gemm + k_dw_reduce"]["launches_per_step"] == 1     # 1 024 rays: one shared launch
     # strong scaling: the global batch is split
     out = subprocess.run(cmd + ["--scaling", "strong"], env=env, capture_output=True, text=True, timeout=160)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -372,6 +372,10 @@ def test_run_nerf_cli_two_ranks(nk, tmp_path):
     assert [t["iter"] for t in train] == [0, 10, 20, 29] and [v["iter"] for v in val] == [15, 29]
     assert train[-1]["loss"] < train[0]["loss"] and all(math.isfinite(v["psnr_8bit"]) and v["psnr"] > 5 for v in val)
     assert "[TRAIN]" in outs[0] and "[TRAIN]" not in outs[1]
+    # once per run: where the multi-rank step's time goes (all-reduce time, library, settings)
+    comm = [r_["comm"] for r_ in recs if "comm" in r_]
+    assert len(comm) == 1 and comm[0]["world"] == 2 and comm[0]["steps"] >= 5 and comm[0]["allreduce_ms"] > 0
+    assert comm[0]["gradient_bytes"] > 0 and "NCCL_ALGO" in comm[0] and "[COMM]" in outs[0]
     ck = out / "checkpoint00029.ckpt"
     assert ck.is_file()
     outs = run("--load-checkpoint", str(ck), "--render-only")

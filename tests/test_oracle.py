@@ -165,3 +165,41 @@ def test_render_rays_in_pieces_equals_whole_batch():
         got = torch.cat([p[k] for p in parts])
         assert torch.allclose(got, whole[k], rtol=1e-5, atol=1e-6), k
     assert torch.equal(torch.cat([p["z_coarse"] for p in parts]), whole["z_coarse"])
+
+
+def test_8bit_saved_tensor_emulation_only_touches_the_weight_gradient():
+    """The oracle's emulation of the HIP path's experimental saved-tensor formats: the forward
+    result and the gradient handed to the layer below are those of the bf16 emulation bit for bit;
+    the weight and bias gradients are the products of the 8-bit copies (checked against a
+    hand-written product for one layer)."""
+    torch.manual_seed(3)
+    arch = O.ARCH_LEGO_CKPT
+    flat = O.NeRFNet.init_flat(arch, 5)
+    x = torch.randn(40, 63).requires_grad_(True)
+    d = torch.randn(40, 27)
+    res = {}
+    for fmt in ("bf16", "fp8", "fp8bf8"):
+        f = flat.clone().requires_grad_(True)
+        xi = x.detach().clone().requires_grad_(True)
+        out = O.NeRFNet.from_flat(arch, f, True, fmt, 2.0 ** 10)(xi, d)
+        (out * torch.linspace(-1, 1, out.numel()).view_as(out)).sum().backward()
+        res[fmt] = (out.detach(), xi.grad.clone(), f.grad.clone())
+    for fmt in ("fp8", "fp8bf8"):
+        assert torch.equal(res[fmt][0], res["bf16"][0])
+        assert torch.equal(res[fmt][1], res["bf16"][1])
+        rel = float((res[fmt][2] - res["bf16"][2]).norm() / res["bf16"][2].norm())
+        assert 1e-4 < rel < 0.1, (fmt, rel)
+    assert float((res["fp8bf8"][2] - res["bf16"][2]).norm()) > float((res["fp8"][2] - res["bf16"][2]).norm())
+    # one layer by hand
+    w = torch.randn(8, 16).requires_grad_(True)
+    b = torch.zeros(8, requires_grad=True)
+    xx = torch.randn(32, 16) * 3
+    g = torch.randn(32, 8) * 1e-3
+    y = O._LinearSaved8.apply(xx, w, b, "fp8bf8", 2.0 ** 12)
+    y.backward(g)
+    gz = (g * 2.0 ** 12).to(torch.float8_e5m2).float() / 2.0 ** 12
+    x8 = xx.to(torch.float8_e4m3fn).float()
+    assert torch.allclose(w.grad, gz.t() @ x8, rtol=1e-6, atol=1e-12)
+    assert torch.allclose(b.grad, gz.sum(0), rtol=1e-6, atol=1e-12)
+    with pytest.raises(ValueError):
+        O.NeRFNet.from_flat(arch, flat, False, "fp8")

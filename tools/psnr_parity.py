@@ -18,6 +18,7 @@ ap.add_argument("--res", type=int, default=32)
 ap.add_argument("--every", type=int, default=100)
 ap.add_argument("--seed", type=int, default=42)
 ap.add_argument("--lr", type=float, default=5e-3)
+ap.add_argument("--act-format", default="bf16", choices=("bf16", "fp8", "fp8bf8"), help="saved-tensor format of the HIP run")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 Nc, Nf = 32, 32
@@ -26,7 +27,7 @@ arch = nk.ARCH_LEGO_CKPT
 oa = O.Arch(arch.depth, arch.width, arch.skip, arch.dir_width, arch.n_freq_xyz, arch.n_freq_dir, arch.relu_first,
             arch.relu_feat, arch.lineage)
 opts = TrainOpts(num_coarse=Nc, num_fine=Nf, num_random_rays=a.rays, perturb=True, radiance_field_noise_std=0.2,
-                 lr=a.lr, seed=a.seed)
+                 lr=a.lr, seed=a.seed, act_format=a.act_format)
 tr = Trainer(arch, arch, opts, dev)
 smp = datasets.RaySampler(scene, a.rays, seed=a.seed)
 fc = _init_flat(arch, a.seed).clone().requires_grad_(True)
