@@ -63,8 +63,9 @@ GEMM_DZ_FEATS, GEMM_ACT_FEATS = 2496, 2592     # features the 11 products read p
 ACT_FORMATS = {"bf16": (2, 2), "fp8": (1, 2), "fp8bf8": (1, 1)}      # bytes per saved activation, per dZ element
 # k_dw_gemm's measured HBM bytes per point ((WRITE_SIZE + 2 x FETCH_SIZE) / points of a launch), from
 # separate rocprofv3 --pmc passes of this command; formats without a pass report traffic null
-PMC_DW_BYTES_PER_POINT = {"bf16": 10206.0}
-PMC_SOURCE = "profiles/r02_kernel_table.csv (separate rocprofv3 --pmc passes of this command), not counted in this run"
+PMC_DW_BYTES_PER_POINT = {"bf16": 10206.0, "fp8bf8": 5118.0}
+PMC_SOURCE = ("profiles/r03_kernel_table*.csv (separate rocprofv3 --pmc passes of this command, tools/profile_bench.sh), "
+              "not counted in this run")
 EV = dict(fwd_c0=0, fwd_c1=1, fwd_f0=2, fwd_f1=3, bwd_fchain0=4, bwd_fchain1=5, bwd_fgemm1=6, bwd_cchain0=7,
           bwd_cchain1=8, bwd_end=9)
 
