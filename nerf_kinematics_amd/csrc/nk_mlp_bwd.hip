@@ -145,45 +145,6 @@ NK_D float bf8_sum8(const TrFrag8& f) {       // sum of the eight e5m2 values
     }
     return s;
 }
-// Operand of the K = 64 form (v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales: twice the 8-bit
-// rate of the K = 16 form): 32 bytes per lane, feature = lane & 31, the 32 points of lane-half
-// lane >> 5.  Which point sits in which byte does not matter as long as A and B agree -- the product
-// sums over all of them -- so lane-half h simply takes the stage's group h, eight points per
-// transposed read.  piece = LDS address of group 0's piece, group_bytes = distance to group 1's.
-struct TrFrag64 { u32x2 v[4]; };
-NK_D void tr_issue64(TrFrag64& f, uint32_t piece, int group_bytes, int tile, int lane) {
-    const int g4 = lane >> 4, i = lane & 15;
-    const int x = 2 * tile + (g4 & 1), sw = (x & 1) << 3;
-    const uint32_t base = piece + (g4 >> 1) * group_bytes + x * 512 + (i & 1) * 8;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t a0 = base + ((8 * r + (i >> 1)) ^ sw) * 16;
-        asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(f.v[r]) : "v"(a0));
-    }
-}
-NK_D void tr_landed(TrFrag64& f) {      // after the wait that covers its reads
-    asm volatile("" : "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2]), "+v"(f.v[3]));
-}
-typedef __attribute__((ext_vector_type(8))) int i32x8;
-NK_D i32x8 tr_value64(const TrFrag64& f) {
-    return i32x8{(int)f.v[0][0], (int)f.v[0][1], (int)f.v[1][0], (int)f.v[1][1], (int)f.v[2][0], (int)f.v[2][1], (int)f.v[3][0], (int)f.v[3][1]};
-}
-// s_waitcnt lgkmcnt(min(n, 15)) for an n known after unrolling (LDS reads return in order)
-NK_D void lgkm_wait_upto(int n) {
-    switch (n < 15 ? n : 15) {
-#define NK_LGKM_CASE(N) case N: asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); break;
-        NK_LGKM_CASE(0) NK_LGKM_CASE(1) NK_LGKM_CASE(2) NK_LGKM_CASE(3) NK_LGKM_CASE(4) NK_LGKM_CASE(5) NK_LGKM_CASE(6) NK_LGKM_CASE(7)
-        NK_LGKM_CASE(8) NK_LGKM_CASE(9) NK_LGKM_CASE(10) NK_LGKM_CASE(11) NK_LGKM_CASE(12) NK_LGKM_CASE(13) NK_LGKM_CASE(14)
-#undef NK_LGKM_CASE
-    default: asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); break;
-    }
-}
-// Measured on the 16 384-ray step (e5m2 x e4m3 products of an 8x256 network): 2.74 ms per launch
-// against 2.51 ms for the K = 16 form -- same results, but the first MFMA of a stage waits for
-// twelve reads instead of six and the stage has no second k-step to read under; stays off.
-#ifndef NK_GEMM8_K64
-#define NK_GEMM8_K64 0
-#endif
 template <int F> struct TrOperand { typedef TrFrag type; };
 template <> struct TrOperand<1> { typedef TrFrag8 type; };
 
@@ -325,141 +286,85 @@ NK_D void gemm_body(const GemmSrc& a, float* slice, char* lds) {
     const bool want_bias = a.want_bias != 0;
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)(NK_LDS char*)lds;
-    for (int64_t s = s0; s < s0 + RING - 1 && s < s1; ++s) issue(s);
-    for (int64_t s = s0; s < s1; ++s) {
-        // loads issued after stage s: those of the stages s+1 .. s+RING-2 that exist
-        const int64_t left = s1 - 1 - s;
-        // (fewer blocks than waves -- thin products in the 8-bit formats: a wave issues one load per
-        // stage or none at all; counting one keeps the loads of the later stages in flight, and a wave
-        // without loads has nothing outstanding, so any count lets it through)
-        constexpr int mp = min_pieces > 0 ? min_pieces : 1;
+    // Stage loop: publish stage s (counted wait + barrier, refill of the slot behind it), then its
+    // k-steps, each read under the MFMAs of the one before.  (Publishing stage s+1 in front of the
+    // LAST k-step of stage s, so that its first operands are read under that k-step's MFMAs, was
+    // measured: bf16 3.80 -> 4.22 ms per launch, e5m2 x e4m3 2.51 -> 2.58 -- the launch is paced by
+    // the arrival of the loads, and an earlier wait only takes MFMAs away from under it.)
+    constexpr int mp = min_pieces > 0 ? min_pieces : 1;
+    // (fewer blocks than waves -- thin products in the 8-bit formats: a wave issues one load per stage
+    // or none at all; counting one keeps the loads of the later stages in flight, and a wave without
+    // loads has nothing outstanding, so any count lets it through)
+    auto publish = [&](int64_t stage) {         // stage has landed for every wave; refill the slot behind it
+        const int64_t left = s1 - 1 - stage;
         if (RING > 4 && left >= 3) gemm_wait_barrier<3 * mp>();
         else if (left >= 2) gemm_wait_barrier<2 * mp>();
         else if (left == 1) gemm_wait_barrier<mp>();
         else gemm_wait_barrier<0>();
-        if (s + RING - 1 < s1) issue(s + RING - 1);
-        if constexpr (FA == 1 && FB == 1 && NK_GEMM8_K64 && TM <= 6) {     // (nine accumulator tiles + 32-byte operands spill)
-            // all-8-bit form: ONE K = 64 MFMA per tile pair and stage.  Reads: the B tiles, then the A
-            // tiles; the MFMAs of A tile i start as soon as its reads have landed (counted lgkmcnt).
-            if (active) {
-                const uint32_t st0 = lds0 + (uint32_t)(s % RING) * stage_bytes;
-                // The tiles of the longer side of the wave tile go through a ring of at most four
-                // operands in flight, the other side's stay resident for the stage.
-                const bool bias_step = want_bias && ((int)(s % WN)) == wn;      // the WN waves of a row take turns
-                auto mma = [&](int i, int j, const i32x8& av, const i32x8& bv) {
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 1 /* A: e5m2 */, 0 /* B: e4m3 */,
-                                                                                0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-                };
-                auto bias_of = [&](int i, const TrFrag64& f) {
+        if (stage + RING - 1 < s1) issue(stage + RING - 1);
+    };
+    constexpr int NKS = 2 * NG;                 // k-steps of a stage (two per group)
+    auto read_step = [&](OpA (&ra)[TM], OpB (&rb)[TN], int64_t stage, int kk) {
+        const uint32_t st0 = lds0 + (uint32_t)(stage % RING) * stage_bytes;
+        const uint32_t pa = st0 + (kk >> 1) * a_blocks * 1024;
+        const uint32_t pb = st0 + a_bytes + (kk >> 1) * b_blocks * 1024;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { TrFrag8 t; t.v = f.v[r]; bsum[i] += bf8_sum8(t); }
-                };
-                if constexpr (TM >= TN) {
-                    constexpr int NR = TM < 4 ? TM : 4;
-                    TrFrag64 fb[TN], fa[NR];
+        for (int i = 0; i < TM; ++i) tr_issue(ra[i], pa, wm * TM + i, kk & 1, lane);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) tr_issue64(fb[j], st0 + a_bytes, b_blocks * 1024, wn * TN + j, lane);
+        for (int j = 0; j < TN; ++j) tr_issue(rb[j], pb, wn * TN + j, kk & 1, lane);
+    };
+    // MFMAs (and this wave's share of the bias sums) of k-step kk of stage s on landed operands
+    auto mma_step = [&](const OpA (&ra)[TM], const OpB (&rb)[TN], int64_t s, int kk) {
+        const bool bias_step = want_bias && (((int)(s & 1) * NKS + kk) % WN) == wn;   // the WN waves of a row take turns
+        if constexpr (FA == 2) {
+            bf16x8 af[TM], bf[TN];
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) tr_issue64(fa[i], st0, a_blocks * 1024, wm * TM + i, lane);
-                    i32x8 bv[TN];
+            for (int i = 0; i < TM; ++i) af[i] = tr_value(ra[i]);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        lgkm_wait_upto(4 * ((i + NR < TM ? i + NR : TM) - 1 - i));      // reads issued after tile i's
-                        if (i == 0) {
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (FB == 2) bf[j] = tr_value(rb[j]);
+                else bf[j] = fp8_to_bf16x8(rb[j]);
+            }
 #pragma unroll
-                            for (int j = 0; j < TN; ++j) { tr_landed(fb[j]); bv[j] = tr_value64(fb[j]); }
-                        }
-                        tr_landed(fa[i % NR]);
-                        const i32x8 av = tr_value64(fa[i % NR]);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) mma(i, j, av, bv[j]);
-                        if (bias_step) bias_of(i, fa[i % NR]);
-                        if (i + NR < TM) tr_issue64(fa[i % NR], st0, a_blocks * 1024, wm * TM + i + NR, lane);
-                    }
-                } else {
-                    constexpr int NR = TN < 4 ? TN : 4;
-                    TrFrag64 fa[TM], fb[NR];
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            if (bias_step) {        // bias gradient: the sum of the A operand over the k-step's points
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) tr_issue64(fa[i], st0, a_blocks * 1024, wm * TM + i, lane);
+                for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                    for (int j = 0; j < NR; ++j) tr_issue64(fb[j], st0 + a_bytes, b_blocks * 1024, wn * TN + j, lane);
-                    i32x8 av[TM];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        lgkm_wait_upto(4 * ((j + NR < TN ? j + NR : TN) - 1 - j));
-                        if (j == 0) {
-#pragma unroll
-                            for (int i = 0; i < TM; ++i) {
-                                tr_landed(fa[i]);
-                                if (bias_step) bias_of(i, fa[i]);
-                                av[i] = tr_value64(fa[i]);
-                            }
-                        }
-                        tr_landed(fb[j % NR]);
-                        const i32x8 bv = tr_value64(fb[j % NR]);
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) mma(i, j, av[i], bv);
-                        if (j + NR < TN) tr_issue64(fb[j % NR], st0 + a_bytes, b_blocks * 1024, wn * TN + j + NR, lane);
+                    for (int w = 0; w < 4; ++w) {
+                        bf16x2 pr; pr[0] = af[i][2 * w]; pr[1] = af[i][2 * w + 1];
+                        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
                     }
                 }
             }
-        } else if (active) {
-            const uint32_t st0 = lds0 + (uint32_t)(s % RING) * stage_bytes;
-            // k-steps of the stage (two per group): the next one is read under this one's MFMAs
-            constexpr int NKS = 2 * NG;
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(tr_value8(ra[i]), tr_value8(rb[j]), acc[i][j], 0, 0, 0);
+            if (bias_step) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) bsum[i] += bf8_sum8(ra[i]);
+            }
+        }
+    };
+    for (int64_t s = s0; s < s0 + RING - 1 && s < s1; ++s) issue(s);
+    for (int64_t s = s0; s < s1; ++s) {
+        publish(s);
+        if (active) {
             OpA fa[2][TM];
             OpB fb[2][TN];
-            auto read_step = [&](int kk, int slot) {
-                const uint32_t pa = st0 + (kk >> 1) * a_blocks * 1024;
-                const uint32_t pb = st0 + a_bytes + (kk >> 1) * b_blocks * 1024;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) tr_issue(fa[slot][i], pa, wm * TM + i, kk & 1, lane);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) tr_issue(fb[slot][j], pb, wn * TN + j, kk & 1, lane);
-            };
-            read_step(0, 0);
+            read_step(fa[0], fb[0], s, 0);
 #pragma unroll
             for (int kk = 0; kk < NKS; ++kk) {
                 const int cur = kk & 1;
                 tr_wait(fa[cur]); tr_wait(fb[cur]);
-                if (kk + 1 < NKS) read_step(kk + 1, cur ^ 1);
-                const bool bias_step = want_bias && (((int)(s & 1) * NKS + kk) % WN) == wn;   // the WN waves of a row take turns
-                if constexpr (FA == 2) {
-                    bf16x8 af[TM], bf[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af[i] = tr_value(fa[cur][i]);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if constexpr (FB == 2) bf[j] = tr_value(fb[cur][j]);
-                        else bf[j] = fp8_to_bf16x8(fb[cur][j]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                    if (bias_step) {        // bias gradient: the sum of the A operand over the k-step's points
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                            for (int w = 0; w < 4; ++w) {
-                                bf16x2 pr; pr[0] = af[i][2 * w]; pr[1] = af[i][2 * w + 1];
-                                bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
-                            }
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(tr_value8(fa[cur][i]), tr_value8(fb[cur][j]),
-                                                                                   acc[i][j], 0, 0, 0);
-                    if (bias_step) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) bsum[i] += bf8_sum8(fa[cur][i]);
-                    }
-                }
+                if (kk + 1 < NKS) read_step(fa[cur ^ 1], fb[cur ^ 1], s, kk + 1);
+                mma_step(fa[cur], fb[cur], s, kk);
             }
         }
     }
