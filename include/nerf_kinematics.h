@@ -124,7 +124,8 @@ const char* nk_last_error(void);
 /* ---- model ------------------------------------------------------------------------------ */
 /* Number of fp32 parameters of `arch` (weights and biases), or a negative nk_status.        */
 int64_t nk_num_params(const nk_arch* arch);
-/* Bytes of the bf16 MFMA-fragment image of one network (forward + transposed streams).      */
+/* Bytes of the bf16 MFMA-fragment image of one network (forward and transposed streams of the
+ * training kernels, and the forward stream in the operand order of the inference kernel).  */
 int64_t nk_packed_bytes(const nk_arch* arch);
 /* fp32 master parameters -> bf16 fragment streams consumed by the MLP kernels.
  * Replaces nothing in the reference (torch keeps fp32 nn.Linear weights); call after every

@@ -59,10 +59,73 @@ __device__ float bwd_weight_elem(const NkPlan& p, const float* __restrict__ prm,
     return prm[l.w_off + m * l.in_dim + in_col];
 }
 
+// Encoding slot -> column of the reference encoding for the 16x16x32 inference stream (the slot
+// order pe16_xyz_frags / pe16_dir_frags produce): slot 32 s + 8 g + j, j < 6 = value j (sin x, y, z,
+// cos x, y, z) of frequency 4 s + g; j = 6, 7 = left-over slot e = 8 s + 2 g + (j - 6): frequencies 8
+// and 9 (e < 12), the raw input (12..14), padding.  Directions: one k-step, frequency g, left-over
+// slots 2 g + (j - 6) = raw input (0..2), padding.
+__device__ int nk16_pe_xyz_col(int slot, int L) {
+    const int s = slot >> 5, g = (slot >> 3) & 3, j = slot & 7;
+    if (j < 6) return 4 * s + g < L ? 3 + 6 * (4 * s + g) + j : -1;
+    const int e = 8 * s + 2 * g + (j - 6);
+    if (e < 12) return 8 + e / 6 < L ? 51 + e : -1;
+    return e < 15 ? e - 12 : -1;
+}
+__device__ int nk16_pe_dir_col(int slot, int L) {
+    const int g = (slot >> 3) & 3, j = slot & 7;
+    if (j < 6) return g < L ? 3 + 6 * g + j : -1;
+    const int e = 2 * g + (j - 6);
+    return e < 3 ? e : -1;
+}
+
+// 16x16x32 inference stream element: layer li, 32-row output tile t, block b of the tile (k-step
+// b >> 1 of 32 inputs, row tile b & 1), lane (row = lane & 15, k quarter kq = lane >> 4), element j
+__device__ float fwd16_weight_elem(const NkPlan& p, const float* __restrict__ prm, int li, int t, int b, int lane, int j) {
+    const NkLayer& l = p.layer[li];
+    const int row = 32 * t + 16 * (b & 1) + (lane & 15), kq = lane >> 4;
+    if (row >= l.out_dim) return 0.0f;
+    int s = b >> 1, seg = 0;
+    while (seg < l.n_seg - 1 && s >= l.seg_steps[seg] / 2) { s -= l.seg_steps[seg] / 2; ++seg; }
+    int col;
+    if (l.seg_type[seg] == NK_SEG_ACT) col = 32 * s + 16 * (j >> 2) + 4 * kq + (j & 3);
+    else if (l.seg_type[seg] == NK_SEG_PEX) col = nk16_pe_xyz_col(32 * s + 8 * kq + j, p.Lx);
+    else col = nk16_pe_dir_col(32 * s + 8 * kq + j, p.Ld);
+    if (col < 0) return 0.0f;
+    col += l.seg_col[seg];
+    if (col >= l.in_dim) return 0.0f;
+    return prm[l.w_off + row * l.in_dim + col];
+}
+
 __global__ __launch_bounds__(64) void k_pack_weights(NkPlan p, const float* __restrict__ prm, char* __restrict__ packed) {
     const int blk = blockIdx.x, lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
     char* dst = packed + (int64_t)blk * 1024;
+    if (blk >= p.fwd_blocks + p.bwd_blocks) {
+        // third stream: the forward stream's block structure in the 16x16x32 form (inference kernel)
+        const int fb = blk - p.fwd_blocks - p.bwd_blocks;
+        int li = 0;
+        while (li + 1 < p.NL && fb >= p.layer[li + 1].fwd_block0) ++li;
+        const NkLayer& l = p.layer[li];
+        const int rel = fb - l.fwd_block0, t = rel / (l.nk + 1), b = rel % (l.nk + 1);
+        if (b == l.nk) {
+            // bias block: float (rt * 4 + g) * 4 + i = bias[32 t + 16 rt + 4 g + i]; rest zero
+            float4 v = make_float4(0, 0, 0, 0);
+            if (lane < 8) {
+                float e[4];
+                for (int k = 0; k < 4; ++k) {
+                    const int row = 32 * t + 16 * (lane >> 2) + 4 * (lane & 3) + k;
+                    e[k] = row < l.out_dim ? prm[l.b_off + row] : 0.0f;
+                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            }
+            *(float4*)(dst + lane * 16) = v;
+            return;
+        }
+        bf16x8 f;
+        for (int j = 0; j < 8; ++j) f[j] = (__bf16)fwd16_weight_elem(p, prm, li, t, b, lane, j);
+        *(bf16x8*)(dst + lane * 16) = f;
+        return;
+    }
     if (blk < p.fwd_blocks) {
         int li = 0;
         while (li + 1 < p.NL && blk >= p.layer[li + 1].fwd_block0) ++li;
@@ -109,7 +172,7 @@ extern "C" int nk_pack_weights(const nk_arch* arch, const float* params, void* p
     NkPlan p;
     int rc = nk_build_plan(arch, &p);
     if (rc < 0) return rc;
-    hipLaunchKernelGGL(k_pack_weights, dim3(p.fwd_blocks + p.bwd_blocks), dim3(64), 0, nk_stream(stream), p, params,
+    hipLaunchKernelGGL(k_pack_weights, dim3(2 * p.fwd_blocks + p.bwd_blocks), dim3(64), 0, nk_stream(stream), p, params,
                        (char*)packed);
     NK_CHECK_LAUNCH("k_pack_weights");
     return NK_OK;
@@ -121,6 +184,7 @@ extern "C" int nk_pack_weights(const nk_arch* arch, const float* params, void* p
 struct FwdArgs {
     NkPlan plan;
     const char* packed;
+    const char* packed16;  // the 16x16x32 inference stream
     const float* rays;     // [R,11]
     const float* z;        // [P]
     float* raw;            // [P,4]
@@ -136,6 +200,7 @@ struct FwdArgs {
 };
 
 #include "nk_fwd_chain.inc"
+#include "nk_fwd16_chain.inc"
 
 
 int64_t nk_act_bytes_fmt(const nk_arch* arch, int64_t R, int32_t n, int act_format) {
@@ -163,6 +228,7 @@ int nk_mlp_forward_fmt(const nk_arch* arch, const void* packed, const float* ray
     int rc = nk_build_plan(arch, &a.plan);
     if (rc < 0) return rc;
     a.packed = (const char*)packed; a.rays = ray_batch; a.z = z; a.raw = raw; a.act = (char*)act_save;
+    a.packed16 = (const char*)packed + (int64_t)(a.plan.fwd_blocks + a.plan.bwd_blocks) * 1024;
     a.P = R * (int64_t)n; a.G = nk_groups(a.P); a.n = n;
     a.live = live_groups; a.n_live = n_live;
 #ifdef NK_STAMPS
@@ -173,8 +239,11 @@ int nk_mlp_forward_fmt(const nk_arch* arch, const void* packed, const float* ray
     a.stagger = env_stagger;
     const dim3 grid((unsigned)(a.G / nw)), block(nw * 64);
     const int fmt = !act_save ? 0 : (act_format == NK_ACT_BF16 ? 1 : 2);
+    // inference runs the 16x16x32 form (NK_FWD16=0: the 32x32x16 form the training kernels use)
+    static const int env_fwd16 = []() { const char* e = getenv("NK_FWD16"); return e ? atoi(e) : 1; }();
 #define NK_FWD_LAUNCH(W_, WD_, NW_, LDS_) do { \
-        if (fmt == 1) hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, 1>), grid, block, LDS_, nk_stream(stream), a); \
+        if (fmt == 0 && env_fwd16) hipLaunchKernelGGL((k_mlp_fwd16<W_, WD_, NW_>), grid, block, LDS_, nk_stream(stream), a); \
+        else if (fmt == 1) hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, 1>), grid, block, LDS_, nk_stream(stream), a); \
         else if (fmt == 2) hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, 2>), grid, block, LDS_, nk_stream(stream), a); \
         else hipLaunchKernelGGL((k_mlp_fwd<W_, WD_, NW_, 0>), grid, block, LDS_, nk_stream(stream), a); } while (0)
     if (a.plan.W == 256) {

@@ -144,5 +144,6 @@ extern "C" int64_t nk_num_params(const nk_arch* arch) {
 extern "C" int64_t nk_packed_bytes(const nk_arch* arch) {
     NkPlan p;
     int rc = nk_build_plan(arch, &p);
-    return rc < 0 ? rc : (int64_t)(p.fwd_blocks + p.bwd_blocks) * 1024;
+    // forward stream, transposed stream, and the forward stream again in the 16x16x32 form of the inference kernel
+    return rc < 0 ? rc : (int64_t)(2 * p.fwd_blocks + p.bwd_blocks) * 1024;
 }

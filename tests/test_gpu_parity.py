@@ -439,3 +439,38 @@ def test_maximum_sizes_and_empty_inputs(nk, dev, lego_w):
         nk.render_rays(torch.zeros(0, 11, device=dev), c, f, num_coarse=64, num_fine=128)
     with pytest.raises(ValueError):
         nk.stratified_z(torch.zeros(0, 11, device=dev), opts)
+
+
+def test_both_inference_forms_agree(nk, dev, lego_w, tmp_path):
+    """Inference runs on the 16x16x32 MFMA form (own weight stream, own encoding slot order), training
+    and NK_FWD16=0 on 32x32x16: same bf16 operands, fp32 accumulation in another order.  A child
+    process renders the probe view with the old form; the maps agree to accumulation-order noise."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "old_form.npy"
+    code = (
+        "import sys, math, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "import nerf_kinematics_amd as nk\nfrom oracle import nerf_oracle as O\n"
+        "dev = torch.device('cuda:0')\n"
+        "w = np.load(%r)\n"
+        "c = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(w['coarse']).to(dev)); f = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(w['fine']).to(dev))\n"
+        "focal = 0.5 * 64 / math.tan(0.5 * 0.6911112070083618)\n"
+        "rb = nk.get_rays(64, 64, focal, O.spherical_pose(45.0, -30.0, 4.0), near=2.0, far=6.0, device=dev)\n"
+        "with torch.no_grad(): r = nk.render_rays(rb, c, f, num_coarse=64, num_fine=128)\n"
+        "np.save(%r, torch.stack([r[0], r[3]]).cpu().numpy())\n"
+    ) % (root, os.path.join(root, "tests", "golden", "lego_lowres3_weights.npz"), str(out))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NK_FWD16="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    old = torch.from_numpy(np.load(str(out)))
+    c = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["coarse"]).to(dev))
+    f = nk.NeRFModel(nk.ARCH_LEGO_CKPT, torch.from_numpy(lego_w["fine"]).to(dev))
+    _, c2w, focal = probe_rays(64, 64)
+    rb = nk.get_rays(64, 64, focal, c2w, near=2.0, far=6.0, device=dev)
+    with torch.no_grad():
+        new = nk.render_rays(rb, c, f, num_coarse=64, num_fine=128)
+    new = torch.stack([new[0], new[3]]).cpu()
+    d = (new - old).abs()
+    print(f"16x16x32 vs 32x32x16 inference: max |d rgb| {float(d.max()):.2e}, mean {float(d.mean()):.2e}")
+    assert not torch.equal(new, old)            # two kernels, not one
+    assert float(d.max()) < 2e-3 and float(d.mean()) < 2e-5
