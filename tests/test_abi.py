@@ -33,8 +33,9 @@ def test_parameter_counts_match_the_reference_checkpoints():
     assert L.nk_num_params(nk.ARCH_LEGO_CKPT.to_c()) == 84548 == nk.ARCH_LEGO_CKPT.num_params()
     assert L.nk_num_params(nk.ARCH_WHEEL_CKPT.to_c()) == 81476 == nk.ARCH_WHEEL_CKPT.num_params()
     assert L.nk_num_params(nk.ARCH_RUN_NERF.to_c()) == 595844 == nk.ARCH_RUN_NERF.num_params()
-    # fragment streams: forward 1 KiB per (tile, k-step) + one bias block per tile, then transposed
-    assert L.nk_packed_bytes(nk.ARCH_RUN_NERF.to_c()) == (1262 + 1100) * 1024
+    # fragment streams: forward 1 KiB per (tile, k-step) + one bias block per tile, then transposed,
+    # then the forward stream again in the operand order of the 16x16x32 inference kernel
+    assert L.nk_packed_bytes(nk.ARCH_RUN_NERF.to_c()) == (1262 + 1100 + 1262) * 1024
 
 
 def test_unsupported_shapes_are_rejected_with_a_message():
