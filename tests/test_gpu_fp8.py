@@ -148,6 +148,28 @@ def test_8bit_gradient_is_bit_reproducible_and_formats_do_not_leak(nk, dev, fmt)
     assert not torch.equal(a[2], ref16[2])
 
 
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_coarse_only_and_tiny_batches_8bit(nk, dev, fmt):
+    """num_fine = 0 (one network, one pass) and batches of 1 and 3 rays: the 8-bit path has no
+    size it cannot take that the bf16 path takes."""
+    arch = nk.ARCH_LEGO_CKPT
+    fc = O.NeRFNet.init_flat(oarch(arch), 1)
+    for R in (1, 3, 40):
+        rb, g = rays(R, 7)
+        target = torch.rand(R, 3, generator=g)
+        grads = {}
+        for f in ("bf16", fmt):
+            c = nk.NeRFModel(arch, fc.to(dev).clone())
+            c.flat.requires_grad_(True)
+            out = nk.render_rays(rb.to(dev), c, None, num_coarse=64, num_fine=0, perturb=True, radiance_field_noise_std=0.2,
+                                 seed=2, act_format=f)
+            ((out[3] - target.to(dev)) ** 2).mean().backward()
+            grads[f] = c.flat.grad.detach().clone()
+        assert torch.isfinite(grads[fmt]).all()
+        rel = float((grads[fmt] - grads["bf16"]).norm() / grads["bf16"].norm())
+        assert 0 < rel < 0.1, (R, rel)
+
+
 def test_8bit_formats_train_like_bf16(nk, dev):
     """400 iterations of the 4x128 pair on a small synthetic scene per format, same seeds: held-out
     PSNR of the 8-bit runs within 1 dB of the bf16 run (trajectories of a chaotic optimisation; the

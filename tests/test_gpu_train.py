@@ -424,7 +424,8 @@ def test_wheel_capture_end_to_end(nk, tmp_path):
     assert (tmp_path / "wheel" / "checkpoint00299.ckpt").is_file()
 
 
-def test_graph_step_equals_eager_step(nk, dev, teacher):
+@pytest.mark.parametrize("fmt", ["bf16", "fp8bf8"])
+def test_graph_step_equals_eager_step(nk, dev, teacher, fmt):
     """GraphedStep (the iteration captured into a HIP graph, per-iteration scalars read from a
     device-resident nk_step_state) against Trainer.step (scalars by value, one launch per kernel):
     same rays, same loss, bit-identical gradient, parameters and Adam moments over six iterations;
