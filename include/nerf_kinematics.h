@@ -42,6 +42,11 @@ typedef enum nk_status {
  *                        (the key order of checkpoint110000.ckpt in
  *                        /root/reference/trained_models/nerf-pytorch/lego-lowres3/)            */
 enum { NK_LINEAGE_RUN_NERF = 0, NK_LINEAGE_FLEXIBLE = 1 };
+/* Without view directions (nk_arch.no_viewdirs, `use_viewdirs: False` of config.yml:55) both
+ * lineages end in ONE linear layer on the last trunk activation whose four rows are
+ * (rgb_raw, sigma_raw): pts_linears.0..D-1, output_linear / layer1, layers_xyz.0..D-2, fc_out.
+ * dir_width and n_freq_dir are then ignored apart from the width pairing the kernels are
+ * compiled for, and columns 8..10 of a ray-batch row are never read.                          */
 
 /* models.coarse / models.fine of config.yml:18-42 */
 typedef struct nk_arch {
@@ -54,6 +59,7 @@ typedef struct nk_arch {
     int32_t relu_first;  /* ReLU after the first trunk layer                           */
     int32_t relu_feat;   /* ReLU after the feature layer                               */
     int32_t lineage;     /* NK_LINEAGE_*                                               */
+    int32_t no_viewdirs; /* 1: no view-direction branch (use_viewdirs: False)                  */
 } nk_arch;
 
 /* Per-iteration scalars of a training step kept in DEVICE memory, so that a step whose launches

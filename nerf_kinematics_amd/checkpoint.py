@@ -63,8 +63,11 @@ def arch_for_state_dict(model_cfg: dict, sd: Dict[str, torch.Tensor]) -> Arch:
     W, in_xyz = sd[first].shape
     if (in_xyz - 3) % 6:
         raise ValueError(f"{first}: input width {in_xyz} is not 3 + 6 L")
-    dirs = "layers_dir.0.weight" if arch.lineage == "flexible" else "views_linears.0.weight"
-    WD, in_views = sd[dirs].shape
+    if arch.use_viewdirs:
+        dirs = "layers_dir.0.weight" if arch.lineage == "flexible" else "views_linears.0.weight"
+        WD, in_views = sd[dirs].shape
+    else:       # no direction branch: its width and encoding are what the model block says (unused)
+        WD, in_views = arch.dir_width, int(W) + arch.in_dir
     skip = arch.skip
     if arch.lineage == "run_nerf":
         skip = -1
@@ -72,7 +75,7 @@ def arch_for_state_dict(model_cfg: dict, sd: Dict[str, torch.Tensor]) -> Arch:
             if sd[f"pts_linears.{i}.weight"].shape[1] == W + in_xyz:
                 skip = i - 1
     return Arch(arch.depth, int(W), skip, int(WD), (int(in_xyz) - 3) // 6, (int(in_views) - int(W) - 3) // 6,
-                arch.relu_first, arch.relu_feat, arch.lineage)
+                arch.relu_first, arch.relu_feat, arch.lineage, arch.use_viewdirs)
 
 
 @dataclass

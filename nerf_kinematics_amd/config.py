@@ -62,17 +62,20 @@ def validate(cfg: dict) -> dict:
     for fn in ("encode_position_fn", "encode_direction_fn"):
         if nerf.get(fn, "positional_encoding") != "positional_encoding":
             raise ConfigError(f"nerf.{fn}: only 'positional_encoding' is supported, got {nerf[fn]!r}")
-    if not nerf.get("use_viewdirs", True):
-        raise ConfigError("nerf.use_viewdirs: false is not supported (the networks take view directions)")
+    vd = bool(nerf.get("use_viewdirs", True))
     for which in ("coarse", "fine"):
         m = cfg["models"].get(which)
         if m is None:
             if which == "coarse":
                 raise ConfigError("models.coarse is required")
             continue
-        for key in ("include_input_xyz", "include_input_dir", "log_sampling_xyz", "log_sampling_dir", "use_viewdirs"):
+        for key in ("include_input_xyz", "include_input_dir", "log_sampling_xyz", "log_sampling_dir"):
             if not m.get(key, True):
                 raise ConfigError(f"models.{which}.{key}: false is not supported")
+        # the ray rows carry view directions exactly when the networks take them (in the reference a
+        # mismatch is a shape error at the first layer of the direction branch)
+        if bool(m.get("use_viewdirs", True)) != vd:
+            raise ConfigError(f"models.{which}.use_viewdirs: {m.get('use_viewdirs', True)} contradicts nerf.use_viewdirs: {vd}")
         if m.get("type") not in ("FlexibleNeRFModel", "NeRF", "run_nerf"):
             raise ConfigError(f"models.{which}.type: unknown model type {m.get('type')!r}")
         if int(m["hidden_size"]) not in (128, 256):

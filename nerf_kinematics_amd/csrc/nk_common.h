@@ -76,12 +76,16 @@ NK_HD int nk_pe_dir_col(int q /* 8*s + j */, int h, int L) {
 }
 
 // ---- network plan ---------------------------------------------------------------------------
-// Layers in forward order: trunk 0..D-1, then ALPHA, FEAT, VIEWS, RGB.
+// Layers in forward order: trunk 0..D-1, then ALPHA, FEAT, VIEWS, RGB.  A network without view
+// directions (NkPlan::no_dirs) keeps the sequence: its output layer sits in ALPHA's place (rows
+// rgb_raw, sigma_raw), the forward kernels leave after that stage, and FEAT, VIEWS and RGB are
+// parameterless (all-zero stream blocks, so the backward chain passes zeros through them).
 enum { NK_SEG_ACT = 0, NK_SEG_PEX = 1, NK_SEG_PED = 2, NK_SEG_DOUT = 3 };
 enum { NK_MAX_LAYERS = 12 };
 
 struct NkLayer {
     int w_off, b_off;       // offsets of weight / bias in the flat fp32 parameter array
+    int has_params;         // 0: the layer is a placeholder of a network without view directions
     int out_dim, in_dim;    // shape of the reference weight matrix [out_dim, in_dim]
     int n_tiles;            // 32-row output tiles
     int n_seg;              // forward K segments, in k-step order
@@ -97,7 +101,7 @@ struct NkLayer {
 };
 
 struct NkPlan {
-    int D, W, WD, skip, Lx, Ld, relu_first, relu_feat, lineage;
+    int D, W, WD, skip, Lx, Ld, relu_first, relu_feat, lineage, no_dirs;
     int NL;                 // D + 4
     NkLayer layer[NK_MAX_LAYERS];
     int fwd_blocks, bwd_blocks;   // stream lengths in 1-KiB blocks

@@ -688,6 +688,15 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
     const NkLayer& lfeat = p.layer[D + 1];
     const NkLayer& lalpha = p.layer[D];
     const int pex0 = 3 + 6 * p.Lx;          // width of gamma(x) inside a skip layer's input
+    if (p.no_dirs) {
+        // no view directions: the only product above the trunk is the output layer's, rows 0..3 of dOut
+        // against h_{D-1}.  It runs as the feature-layer product below with that layer's dZ segment (all
+        // zeros here) switched off in the reduction, so no further tile shape is compiled for it.
+        GemmDst d[2][2] = {};
+        d[1][0] = gemm_dst(lalpha.w_off, lalpha.in_dim, 0, 4, NK_COL_IDENT, 0, W, 0);
+        d[1][0].row_tiled = 0;              // the dOut tile keeps its rows in ascending order
+        queue_gemm(q, dz(2), W, dz(0), 32, act(2 + D - 1), W, nullptr, 0, G, grad, d, -1, lalpha.b_off);
+    } else {
     {   // rgb: rows 0..2 of dOut against g
         GemmDst d[2][2] = {};
         d[0][0] = gemm_dst(lrgb.w_off, lrgb.in_dim, 0, 3, NK_COL_IDENT, 0, WD, 0);
@@ -706,6 +715,7 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
         d[1][0] = gemm_dst(lalpha.w_off, lalpha.in_dim, 3, 1, NK_COL_IDENT, 0, W, 0);
         d[1][0].row_tiled = 0;              // (dOut tile)
         queue_gemm(q, dz(2), W, dz(0), 32, act(2 + D - 1), W, nullptr, 0, G, grad, d, lfeat.b_off, lalpha.b_off);
+    }
     }
     for (int L = D - 1; L >= 0; --L) {     // trunk
         const NkLayer& l = p.layer[L];

@@ -23,7 +23,7 @@
 __device__ float fwd_weight_elem(const NkPlan& p, const float* __restrict__ prm, int li, int t, int ks, int r, int h, int j) {
     const NkLayer& l = p.layer[li];
     const int row = 32 * t + r;
-    if (row >= l.out_dim) return 0.0f;
+    if (row >= l.out_dim || !l.has_params) return 0.0f;
     int s = ks, seg = 0;
     while (seg < l.n_seg - 1 && s >= l.seg_steps[seg]) { s -= l.seg_steps[seg]; ++seg; }
     int col;
@@ -45,14 +45,19 @@ __device__ float bwd_weight_elem(const NkPlan& p, const float* __restrict__ prm,
     const NkLayer& l = p.layer[li];
     const int L_ALPHA = p.D, L_FEAT = p.D + 1, L_RGB = p.D + 3;
     const int in_col = l.bwd_act_col + 32 * ti + r;
+    if (li == L_FEAT && ks == l.bwd_nk - 1) { // extra dOut k-step: k = 3 is d sigma_raw -> alpha row
+        const NkLayer& a = p.layer[L_ALPHA];
+        if (p.no_dirs) {                      // ... k = 0..3 -> the four rows of the output layer
+            if (h != 0 || j > 3) return 0.0f;
+            return prm[a.w_off + j * a.in_dim + 32 * ti + r];
+        }
+        if (h != 0 || j != 3) return 0.0f;
+        return prm[a.w_off + 32 * ti + r];
+    }
+    if (!l.has_params) return 0.0f;
     if (li == L_RGB) {                       // single dOut k-step: k = 0..2 are d rgb_raw
         if (h != 0 || j >= 3) return 0.0f;
         return prm[l.w_off + j * l.in_dim + in_col];
-    }
-    if (li == L_FEAT && ks == l.bwd_nk - 1) { // extra dOut k-step: k = 3 is d sigma_raw -> alpha row
-        if (h != 0 || j != 3) return 0.0f;
-        const NkLayer& a = p.layer[L_ALPHA];
-        return prm[a.w_off + 32 * ti + r];
     }
     const int m = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
     if (m >= l.out_dim) return 0.0f;
@@ -83,7 +88,7 @@ __device__ int nk16_pe_dir_col(int slot, int L) {
 __device__ float fwd16_weight_elem(const NkPlan& p, const float* __restrict__ prm, int li, int t, int b, int lane, int j) {
     const NkLayer& l = p.layer[li];
     const int row = 32 * t + 16 * (b & 1) + (lane & 15), kq = lane >> 4;
-    if (row >= l.out_dim) return 0.0f;
+    if (row >= l.out_dim || !l.has_params) return 0.0f;
     int s = b >> 1, seg = 0;
     while (seg < l.n_seg - 1 && s >= l.seg_steps[seg] / 2) { s -= l.seg_steps[seg] / 2; ++seg; }
     int col;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(64) void k_pack_weights(NkPlan p, const float* __re
                 float e[4];
                 for (int k = 0; k < 4; ++k) {
                     const int row = 32 * t + 16 * (lane >> 2) + 4 * (lane & 3) + k;
-                    e[k] = row < l.out_dim ? prm[l.b_off + row] : 0.0f;
+                    e[k] = (row < l.out_dim && l.has_params) ? prm[l.b_off + row] : 0.0f;
                 }
                 v = make_float4(e[0], e[1], e[2], e[3]);
             }
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(64) void k_pack_weights(NkPlan p, const float* __re
                 float e[4];
                 for (int k = 0; k < 4; ++k) {
                     const int row = 32 * t + 8 * q + 4 * hh + k;
-                    e[k] = row < l.out_dim ? prm[l.b_off + row] : 0.0f;
+                    e[k] = (row < l.out_dim && l.has_params) ? prm[l.b_off + row] : 0.0f;
                 }
                 v = make_float4(e[0], e[1], e[2], e[3]);
             }

@@ -33,7 +33,7 @@ int nk_waves_per_wg(int backward) {
 }
 
 extern "C" const char* nk_last_error(void) { return g_err; }
-extern "C" int nk_version(void) { return 101; }
+extern "C" int nk_version(void) { return 102; }
 
 int nk_build_plan(const nk_arch* a, NkPlan* p) {
     if (!a || !p) NK_FAIL(NK_ERR_ARG, "nk_build_plan: null argument");
@@ -52,6 +52,7 @@ int nk_build_plan(const nk_arch* a, NkPlan* p) {
     memset(p, 0, sizeof(*p));
     p->D = D; p->W = W; p->WD = WD; p->skip = a->skip; p->Lx = a->n_freq_xyz; p->Ld = a->n_freq_dir;
     p->relu_first = a->relu_first != 0; p->relu_feat = a->relu_feat != 0; p->lineage = a->lineage;
+    p->no_dirs = a->no_viewdirs != 0;
     p->NL = D + 4;
     const int in_xyz = 3 + 6 * p->Lx, in_dir = 3 + 6 * p->Ld;
     const int L_ALPHA = D, L_FEAT = D + 1, L_VIEWS = D + 2, L_RGB = D + 3;
@@ -72,8 +73,8 @@ int nk_build_plan(const nk_arch* a, NkPlan* p) {
             l.seg_type[0] = NK_SEG_ACT; l.seg_steps[0] = W / 16; l.seg_col[0] = 0;
         }
     }
-    {
-        NkLayer& l = p->layer[L_ALPHA]; l.out_dim = 1; l.in_dim = W; l.n_seg = 1;
+    {   // (without view directions: the output layer, rows rgb_raw, sigma_raw)
+        NkLayer& l = p->layer[L_ALPHA]; l.out_dim = p->no_dirs ? 4 : 1; l.in_dim = W; l.n_seg = 1;
         l.seg_type[0] = NK_SEG_ACT; l.seg_steps[0] = W / 16; l.seg_col[0] = 0;
     }
     {
@@ -90,10 +91,18 @@ int nk_build_plan(const nk_arch* a, NkPlan* p) {
         l.seg_type[0] = NK_SEG_ACT; l.seg_steps[0] = WD / 16; l.seg_col[0] = 0;
     }
 
-    // parameter offsets in state-dict order
+    // parameter offsets in state-dict order.  Without view directions the three layers of the
+    // direction branch keep their place in the streams (same stage sequence, all-zero blocks) but
+    // own no parameters.
+    for (int i = 0; i < p->NL; ++i) p->layer[i].has_params = 1;
     int order[NK_MAX_LAYERS], n = 0;
     for (int i = 0; i < D; ++i) order[n++] = i;
-    if (a->lineage == NK_LINEAGE_RUN_NERF) {
+    if (p->no_dirs) {
+        order[n++] = L_ALPHA;
+        p->layer[L_FEAT].has_params = p->layer[L_VIEWS].has_params = p->layer[L_RGB].has_params = 0;
+        p->layer[L_FEAT].w_off = p->layer[L_VIEWS].w_off = p->layer[L_RGB].w_off = -1;
+        p->layer[L_FEAT].b_off = p->layer[L_VIEWS].b_off = p->layer[L_RGB].b_off = -1;
+    } else if (a->lineage == NK_LINEAGE_RUN_NERF) {
         order[n++] = L_VIEWS; order[n++] = L_FEAT; order[n++] = L_ALPHA; order[n++] = L_RGB;
     } else {
         order[n++] = L_VIEWS; order[n++] = L_ALPHA; order[n++] = L_RGB; order[n++] = L_FEAT;

@@ -27,7 +27,7 @@ STREAM_STRATIFIED, STREAM_PDF, STREAM_NOISE_COARSE, STREAM_NOISE_FINE, STREAM_PI
 
 class NkArch(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("depth", "width", "skip", "dir_width", "n_freq_xyz", "n_freq_dir",
-                                         "relu_first", "relu_feat", "lineage")]
+                                         "relu_first", "relu_feat", "lineage", "no_viewdirs")]
 
 
 class NkStepState(C.Structure):

@@ -10,6 +10,10 @@ Two nerf-pytorch lineages are supported (``lineage``):
                key names of its checkpoints (``layer1``, ``layers_xyz.N``, ``layers_dir.0``,
                ``fc_alpha``, ``fc_rgb``, ``fc_feat``).
 
+``use_viewdirs=False`` (``models.*.use_viewdirs`` of the same file, line 39) drops the direction
+branch of either lineage: the trunk is followed by ONE linear layer with four rows
+(rgb_raw, sigma_raw), ``output_linear`` / ``fc_out`` in the public nerf-pytorch sources.
+
 Parameters live in ONE flat fp32 tensor in state-dict order; the MFMA kernels read a bf16
 fragment image of it (``NeRFModel.pack``), refreshed after every optimiser step.
 """
@@ -35,6 +39,7 @@ class Arch:
     relu_first: bool = True
     relu_feat: bool = False
     lineage: str = "run_nerf"
+    use_viewdirs: bool = True
 
     @property
     def in_xyz(self) -> int:
@@ -47,7 +52,8 @@ class Arch:
     def to_c(self) -> _lib.NkArch:
         return _lib.NkArch(self.depth, self.width, self.skip, self.dir_width, self.n_freq_xyz, self.n_freq_dir,
                            int(self.relu_first), int(self.relu_feat),
-                           _lib.NK_LINEAGE_FLEXIBLE if self.lineage == "flexible" else _lib.NK_LINEAGE_RUN_NERF)
+                           _lib.NK_LINEAGE_FLEXIBLE if self.lineage == "flexible" else _lib.NK_LINEAGE_RUN_NERF,
+                           int(not self.use_viewdirs))
 
     def param_shapes(self) -> List[Tuple[str, Tuple[int, int]]]:
         """[(module name, (out, in))] in state-dict order."""
@@ -59,9 +65,13 @@ class Arch:
         dirs = (self.dir_width, W + self.in_dir)
         if self.lineage == "flexible":
             names = [("layer1", trunk[0])] + [(f"layers_xyz.{i - 1}", trunk[i]) for i in range(1, D)]
+            if not self.use_viewdirs:
+                return names + [("fc_out", (4, W))]
             names += [("layers_dir.0", dirs), ("fc_alpha", (1, W)), ("fc_rgb", (3, self.dir_width)), ("fc_feat", (W, W))]
         else:
             names = [(f"pts_linears.{i}", trunk[i]) for i in range(D)]
+            if not self.use_viewdirs:
+                return names + [("output_linear", (4, W))]
             names += [("views_linears.0", dirs), ("feature_linear", (W, W)), ("alpha_linear", (1, W)),
                       ("rgb_linear", (3, self.dir_width))]
         return names
@@ -80,6 +90,9 @@ class Arch:
         W = int(model_cfg.get("hidden_size", 256))
         lx = int(model_cfg.get("num_encoding_fn_xyz", 10))
         ld = int(model_cfg.get("num_encoding_fn_dir", 4))
+        vd = bool(model_cfg.get("use_viewdirs", True))
+        if state_dict is not None:      # a stored network says itself whether it has a direction branch
+            vd = not any(k in state_dict for k in ("fc_out.weight", "output_linear.weight"))
         if typ == "FlexibleNeRFModel":
             # The reference's training script builds this class with its default depth whatever the
             # file says: both vendored checkpoints hold layer1 + three layers_xyz under
@@ -96,11 +109,12 @@ class Arch:
                               "honoured (the reference trains 4 trunk layers whatever they say); building 4 layers. "
                               "Set honour_num_layers: true in the model block to build the depth named.", stacklevel=2)
             return Arch(depth=depth, width=W, skip=-1, dir_width=W // 2, n_freq_xyz=lx, n_freq_dir=ld,
-                        relu_first=False, relu_feat=True, lineage="flexible")
+                        relu_first=False, relu_feat=True, lineage="flexible", use_viewdirs=vd)
         if typ in ("NeRF", "run_nerf"):
             D = int(model_cfg.get("num_layers", 8))
             return Arch(depth=D, width=W, skip=int(model_cfg.get("skip", 4 if D > 5 else -1)), dir_width=W // 2,
-                        n_freq_xyz=lx, n_freq_dir=ld, relu_first=True, relu_feat=False, lineage="run_nerf")
+                        n_freq_xyz=lx, n_freq_dir=ld, relu_first=True, relu_feat=False, lineage="run_nerf",
+                        use_viewdirs=vd)
         raise ValueError(f"unknown model type {typ!r}")
 
 

@@ -33,6 +33,19 @@ def _f32(t: torch.Tensor, name: str, shape=None) -> torch.Tensor:
     return t.contiguous()
 
 
+def _ray_rows(ray_batch: torch.Tensor, takes_dirs: bool = False) -> torch.Tensor:
+    """Ray-batch rows for the kernels: ``[o(3) d(3) near far viewdir(3)]``, 11 floats.  The reference's
+    8-column rows ``[o d near far]`` (``use_viewdirs: False``) are accepted wherever the view direction
+    is not needed (``takes_dirs`` false: every stage but a network with a direction branch) and widened
+    with zeros; the kernels address rows of 11 floats and never read columns 8..10 in those places."""
+    if isinstance(ray_batch, torch.Tensor) and ray_batch.dim() == 2 and ray_batch.shape[1] == 8:
+        if takes_dirs:
+            raise ValueError("ray_batch: 8-column rows carry no view directions, but the network has a direction "
+                             "branch (use_viewdirs); expected shape (None, 11)")
+        return torch.nn.functional.pad(_f32(ray_batch, "ray_batch", (None, 8)), (0, 3))
+    return _f32(ray_batch, "ray_batch", (None, 11))
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -99,7 +112,7 @@ def get_rays(H: int, W: int, focal, c2w: torch.Tensor, *, near: float, far: floa
 
 def stratified_z(ray_batch: torch.Tensor, opts: _lib.NkRenderOpts) -> torch.Tensor:
     L = _lib.load()
-    rb = _f32(ray_batch, "ray_batch", (None, 11))
+    rb = _ray_rows(ray_batch)
     z = torch.empty(rb.shape[0], opts.num_coarse, dtype=torch.float32, device=rb.device)
     with torch.cuda.device(rb.device):
         _lib.check(L.nk_stratified_z(rb.data_ptr(), rb.shape[0], opts, z.data_ptr(), _stream(rb.device)))
@@ -110,7 +123,7 @@ def run_network(model: NeRFModel, ray_batch: torch.Tensor, z: torch.Tensor,
                 act_save: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Embedder + MLP on the points ``o + d z``: raw [R, n, 4] = (rgb_raw, sigma_raw)."""
     L = _lib.load()
-    rb = _f32(ray_batch, "ray_batch", (None, 11))
+    rb = _ray_rows(ray_batch, model.arch.use_viewdirs)
     z = _f32(z, "z", (rb.shape[0], None))
     model.ensure_packed()
     R, n = z.shape
@@ -124,7 +137,7 @@ def run_network(model: NeRFModel, ray_batch: torch.Tensor, z: torch.Tensor,
 def raw2outputs(raw: torch.Tensor, z: torch.Tensor, ray_batch: torch.Tensor, opts: _lib.NkRenderOpts,
                 noise_stream: int = _lib.STREAM_NOISE_FINE) -> Dict[str, torch.Tensor]:
     L = _lib.load()
-    rb = _f32(ray_batch, "ray_batch", (None, 11))
+    rb = _ray_rows(ray_batch)
     R = rb.shape[0]
     z = _f32(z, "z", (R, None))
     n = z.shape[1]
@@ -142,7 +155,7 @@ def raw2outputs(raw: torch.Tensor, z: torch.Tensor, ray_batch: torch.Tensor, opt
 
 def raw2outputs_backward(raw, z, ray_batch, opts, noise_stream, d_rgb, d_acc=None, d_depth=None) -> torch.Tensor:
     L = _lib.load()
-    rb = _f32(ray_batch, "ray_batch", (None, 11))
+    rb = _ray_rows(ray_batch)
     R = rb.shape[0]
     z = _f32(z, "z", (R, None))
     n = z.shape[1]
@@ -251,6 +264,8 @@ def render_rays(ray_batch: torch.Tensor, coarse: NeRFModel, fine: Optional[NeRFM
                 training: Optional[bool] = None, act_format: str = "bf16", skip_empty_eps: float = 0.0):
     """Volume-render rays: returns ``(rgb_fine, disp_fine, acc_fine, rgb_coarse, disp_coarse, acc_coarse)``.
 
+    ``ray_batch``: float32 ``[R, 11]`` rows ``[o d near far viewdir]``, or ``[R, 8]`` without the view
+    direction when neither network has a direction branch (``Arch.use_viewdirs`` false).
     With ``num_fine == 0`` the fine slots repeat the coarse maps.  Differentiable w.r.t.
     ``coarse.flat`` and ``fine.flat`` (through the rgb maps) when they require grad.
 
@@ -258,11 +273,11 @@ def render_rays(ray_batch: torch.Tensor, coarse: NeRFModel, fine: Optional[NeRFM
     "fp8bf8") saves the tensors backward needs in 8-bit formats (training calls), and
     ``skip_empty_eps`` > 0 skips the fine network where the coarse pass found nothing (inference calls).
     """
-    rb = _f32(ray_batch, "ray_batch", (None, 11))
     if num_fine > 0 and fine is None:
         raise ValueError("render_rays: num_fine > 0 needs a fine model")
     if num_fine == 0:
         fine = None
+    rb = _ray_rows(ray_batch, coarse.arch.use_viewdirs or (fine is not None and fine.arch.use_viewdirs))
     opts = make_opts(num_coarse, num_fine, perturb, lindisp, radiance_field_noise_std, white_background, seed,
                      act_format=act_format, skip_empty_eps=skip_empty_eps)
     if training is None:

@@ -194,6 +194,11 @@ class Arch:
     ``skip+1`` takes cat[gamma(x), h]; ``alpha_linear``; ``feature_linear`` (no ReLU);
     ``views_linears.0`` on cat[feat, gamma(d)] + ReLU; ``rgb_linear``.  Parameter order:
     pts_linears, views_linears, feature_linear, alpha_linear, rgb_linear.
+
+    ``use_viewdirs=False`` (``models.*.use_viewdirs``, config.yml:39, and ``nerf.use_viewdirs``, :55):
+    either lineage without its direction branch, the trunk followed by one four-row linear layer
+    (rgb_raw, sigma_raw) called ``fc_out`` / ``output_linear`` in the public nerf-pytorch sources;
+    ray-batch rows then have 8 columns.  Parity unpinned: the reference ships no such network.
     """
     depth: int = 8
     width: int = 256
@@ -204,6 +209,7 @@ class Arch:
     relu_first: bool = True
     relu_feat: bool = False
     lineage: str = "run_nerf"   # or "flexible"
+    use_viewdirs: bool = True
 
     @property
     def in_xyz(self) -> int:
@@ -224,10 +230,14 @@ class Arch:
         if self.lineage == "flexible":
             names = [("layer1", trunk[0])]
             names += [(f"layers_xyz.{i - 1}", trunk[i]) for i in range(1, D)]
+            if not self.use_viewdirs:
+                return names + [("fc_out", (4, W))]
             names += [("layers_dir.0", dir_shape), ("fc_alpha", (1, W)),
                       ("fc_rgb", (3, self.dir_width)), ("fc_feat", (W, W))]
         else:
             names = [(f"pts_linears.{i}", trunk[i]) for i in range(D)]
+            if not self.use_viewdirs:
+                return names + [("output_linear", (4, W))]
             names += [("views_linears.0", dir_shape), ("feature_linear", (W, W)),
                       ("alpha_linear", (1, W)), ("rgb_linear", (3, self.dir_width))]
         return names
@@ -355,8 +365,9 @@ class NeRFNet:
             return _RoundGradBf16.apply(x @ w.t() + b)
         return x @ w.t() + b
 
-    def __call__(self, x_enc: torch.Tensor, d_enc: torch.Tensor) -> torch.Tensor:
-        """x_enc [P, in_xyz], d_enc [P, in_dir] -> raw [P, 4] = (rgb_raw(3), sigma_raw(1))."""
+    def __call__(self, x_enc: torch.Tensor, d_enc: Optional[torch.Tensor]) -> torch.Tensor:
+        """x_enc [P, in_xyz], d_enc [P, in_dir] (None without view directions) -> raw [P, 4] =
+        (rgb_raw(3), sigma_raw(1))."""
         a = self.arch
         flex = a.lineage == "flexible"
         tname = (lambda i: "layer1" if i == 0 else f"layers_xyz.{i - 1}") if flex else (lambda i: f"pts_linears.{i}")
@@ -367,6 +378,8 @@ class NeRFNet:
             h = self._lin(tname(i), h)
             if i > 0 or a.relu_first:
                 h = torch.relu(h)
+        if not a.use_viewdirs:
+            return self._lin("fc_out" if flex else "output_linear", h)
         sigma = self._lin("fc_alpha" if flex else "alpha_linear", h)
         feat = self._lin("fc_feat" if flex else "feature_linear", h)
         if a.relu_feat:
@@ -463,17 +476,20 @@ class RenderOpts:
 def _run_net(net: NeRFNet, ray_batch: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     a = net.arch
     o, d = ray_batch[:, 0:3], ray_batch[:, 3:6]
-    vd = ray_batch[:, 8:11]
     pts = o[:, None, :] + d[:, None, :] * z[..., None]
     R, n = z.shape
     x_enc = positional_encoding(pts.reshape(-1, 3), a.n_freq_xyz)
-    d_enc = positional_encoding(vd[:, None, :].expand(R, n, 3).reshape(-1, 3), a.n_freq_dir)
+    d_enc = None
+    if a.use_viewdirs:
+        vd = ray_batch[:, 8:11]
+        d_enc = positional_encoding(vd[:, None, :].expand(R, n, 3).reshape(-1, 3), a.n_freq_dir)
     return net(x_enc, d_enc).reshape(R, n, 4)
 
 
 def render_rays(ray_batch: torch.Tensor, coarse: NeRFNet, fine: Optional[NeRFNet], opts: RenderOpts,
                 ray_offset: int = 0) -> Dict[str, torch.Tensor]:
-    """Volume-render a batch of rays.  ray_batch [R,11] -> dict with fine and coarse maps.
+    """Volume-render a batch of rays.  ray_batch [R,11] ([R,8] for networks without view directions)
+    -> dict with fine and coarse maps.
 
     Random draws (only when ``perturb`` / noise are on) come from the shared hash streams,
     indexed ``ray*n + sample``.  ``ray_offset``: index of the first row inside a larger batch, so

@@ -52,6 +52,8 @@ def test_stored_learning_rate_is_reproduced(golden_dir):
     (lambda c: c["nerf"]["train"].__setitem__("num_coarse", 1), "num_coarse"),
     (lambda c: c["nerf"]["train"].__setitem__("act_format", "fp4"), "act_format"),
     (lambda c: c["nerf"]["validation"].__setitem__("skip_empty_eps", -1.0), "skip_empty_eps"),
+    (lambda c: c["nerf"].__setitem__("use_viewdirs", False), "use_viewdirs"),      # the model blocks still say True
+    (lambda c: c["models"]["fine"].__setitem__("use_viewdirs", False), "use_viewdirs"),
 ])
 def test_unsupported_config_is_named(golden_dir, tmp_path, edit, key):
     import yaml
@@ -75,6 +77,46 @@ def test_experiment_keys_default_off_and_reach_the_render_options(golden_dir):
     assert TrainOpts.from_config(cfg).act_format == "fp8bf8"
     assert config_mod.render_kwargs(cfg, "validation")["skip_empty_eps"] == 1e-3
     assert "skip_empty_eps" not in config_mod.render_kwargs(cfg, "train")
+
+
+def test_use_viewdirs_false_builds_networks_without_the_direction_branch(golden_dir, tmp_path):
+    """nerf.use_viewdirs and models.*.use_viewdirs (config.yml:39,55 of the reference's files) all False:
+    either lineage ends in one four-row layer; a checkpoint written for such a pair has those key names,
+    loads into a plain torch module tree of the public model class, and round-trips bit-exactly."""
+    off = {"nerf": {"use_viewdirs": False}, "models": {"coarse": {"use_viewdirs": False}, "fine": {"use_viewdirs": False}}}
+    cfg = config_mod.load_config(os.path.join(golden_dir, "lego-lowres3_config.yml"), off)
+    arch = Arch.from_config(cfg["models"]["fine"])
+    assert not arch.use_viewdirs and arch.to_c().no_viewdirs == 1 and ARCH_RUN_NERF.to_c().no_viewdirs == 0
+    assert [n for n, _ in arch.param_shapes()] == ["layer1", "layers_xyz.0", "layers_xyz.1", "layers_xyz.2", "fc_out"]
+    big = Arch.from_config({"type": "NeRF", "hidden_size": 256, "num_layers": 8, "use_viewdirs": False})
+    assert [n for n, _ in big.param_shapes()][-2:] == ["pts_linears.7", "output_linear"]
+    assert big.num_params() == ARCH_RUN_NERF.num_params() - (283 * 128 + 128) - (256 * 256 + 256) - 257 - (3 * 128 + 3) + 4 * 257
+    n = arch.num_params()
+    g = torch.Generator().manual_seed(2)
+    s = ckpt.TrainState(3, torch.randn(n, generator=g), torch.randn(n, generator=g),
+                        [torch.randn(n, generator=g) for _ in range(2)], [torch.rand(n, generator=g) for _ in range(2)],
+                        4, 5e-4, 0.01, 20.0)
+    path = str(tmp_path / "novd.ckpt")
+    ckpt.save_checkpoint(path, s, arch, arch)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+
+    class Flexible(torch.nn.Module):                # FlexibleNeRFModel(use_viewdirs=False): module names only
+        def __init__(self):
+            super().__init__()
+            lin = torch.nn.Linear
+            self.layer1 = lin(63, 128)
+            self.layers_xyz = torch.nn.ModuleList([lin(128, 128) for _ in range(3)])
+            self.fc_out = lin(128, 4)
+    m = Flexible()
+    m.load_state_dict(ck["model_fine_state_dict"], strict=True)
+    assert torch.equal(torch.cat([p.detach().reshape(-1) for p in m.parameters()]), s.fine)
+    back = ckpt.state_from_checkpoint(ckpt.load_checkpoint(path), arch, arch)
+    assert torch.equal(back.coarse, s.coarse) and torch.equal(back.fine, s.fine)
+    assert torch.equal(back.exp_avg[1], s.exp_avg[1]) and torch.equal(back.exp_avg_sq[0], s.exp_avg_sq[0])
+    sd = ck["model_coarse_state_dict"]
+    assert ckpt.arch_for_state_dict(cfg["models"]["coarse"], sd) == arch
+    # a stored network decides by its keys, whatever the model block says
+    assert ckpt.arch_for_state_dict(dict(cfg["models"]["coarse"], use_viewdirs=True), sd) == arch
 
 
 def test_config_round_trip(golden_dir, tmp_path):

@@ -203,3 +203,36 @@ def test_8bit_saved_tensor_emulation_only_touches_the_weight_gradient():
     assert torch.allclose(b.grad, gz.sum(0), rtol=1e-6, atol=1e-12)
     with pytest.raises(ValueError):
         O.NeRFNet.from_flat(arch, flat, False, "fp8")
+
+
+def test_network_without_view_directions():
+    """use_viewdirs False: the trunk followed by one four-row layer; rows of 8 columns; the direction
+    columns of an 11-column row are not looked at; gradients reach the output layer."""
+    for base in (O.ARCH_LEGO_CKPT, O.ARCH_RUN_NERF):
+        arch = O.Arch(base.depth, base.width, base.skip, base.dir_width, base.n_freq_xyz, base.n_freq_dir,
+                      base.relu_first, base.relu_feat, base.lineage, use_viewdirs=False)
+        names = [n for n, _ in arch.param_shapes()]
+        assert names[-1] == ("fc_out" if base.lineage == "flexible" else "output_linear") and len(names) == base.depth + 1
+        flat = O.NeRFNet.init_flat(arch, 5).requires_grad_(True)
+        net = O.NeRFNet.from_flat(arch, flat)
+        ro, rd = O.get_rays(4, 4, 10.0, O.spherical_pose(30.0, -20.0, 4.0))
+        rb8 = O.make_ray_batch(ro, rd, 2.0, 6.0, use_viewdirs=False)
+        rb11 = O.make_ray_batch(ro, rd, 2.0, 6.0)
+        assert rb8.shape == (16, 8) and torch.equal(rb11[:, :8], rb8)
+        a = O.render_rays(rb8, net, net, O.RenderOpts(16, 8))
+        b = O.render_rays(rb11, net, net, O.RenderOpts(16, 8))
+        assert torch.equal(a["rgb_fine"], b["rgb_fine"]) and a["raw_fine"].shape == (16, 24, 4)
+        # by hand: h through the trunk, then the four rows
+        x = O.positional_encoding((rb8[:, None, 0:3] + rb8[:, None, 3:6] * a["z_all"][..., None]).reshape(-1, 3), arch.n_freq_xyz)
+        h = x
+        for i in range(arch.depth):
+            nm = ("layer1" if i == 0 else f"layers_xyz.{i - 1}") if arch.lineage == "flexible" else f"pts_linears.{i}"
+            if arch.skip >= 0 and i == arch.skip + 1:
+                h = torch.cat([x, h], -1)
+            h = h @ net.p[nm + ".weight"].t() + net.p[nm + ".bias"]
+            if i > 0 or arch.relu_first:
+                h = torch.relu(h)
+        raw = h @ net.p[names[-1] + ".weight"].t() + net.p[names[-1] + ".bias"]
+        torch.testing.assert_close(raw.reshape(16, 24, 4), a["raw_fine"], rtol=1e-5, atol=1e-6)
+        a["raw_fine"].square().sum().backward()
+        assert float((flat.grad[-4 * (arch.width + 1):] != 0).float().mean()) > 0.3
