@@ -79,7 +79,8 @@ NK_HD int nk_pe_dir_col(int q /* 8*s + j */, int h, int L) {
 // Layers in forward order: trunk 0..D-1, then ALPHA, FEAT, VIEWS, RGB.  A network without view
 // directions (NkPlan::no_dirs) keeps the sequence: its output layer sits in ALPHA's place (rows
 // rgb_raw, sigma_raw), the forward kernels leave after that stage, and FEAT, VIEWS and RGB are
-// parameterless (all-zero stream blocks, so the backward chain passes zeros through them).
+// parameterless (all-zero blocks in the forward streams, which are never consumed; absent from the
+// transposed stream: the backward chain starts at FEAT's stage with dOut as its only operand).
 enum { NK_SEG_ACT = 0, NK_SEG_PEX = 1, NK_SEG_PED = 2, NK_SEG_DOUT = 3 };
 enum { NK_MAX_LAYERS = 12 };
 

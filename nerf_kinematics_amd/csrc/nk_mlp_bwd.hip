@@ -190,11 +190,13 @@ struct ReduceBatch { GemmOut g[NK_REDUCE_BATCH]; const float* partial; };
 // of the same layer.
 //   width 256: trunk, trunk 0, rgb, feature + alpha, skip (h + gamma(x)), views (feat + gamma(d))
 //   width 128: the same six
+//   width 256 without view directions: the output layer (dOut against h_{D-1}); width 128 uses 1 x 4
 #define NK_GEMM_SHAPES(X) \
     X(0, 8, 8, 2, 4, 1455, 1397, 1833) X(1, 8, 2, 4, 2, 921, 820, 976) X(2, 1, 4, 1, 4, 571, 474, 634) \
     X(3, 9, 8, 1, 8, 1589, 1510, 2082) X(4, 8, 10, 4, 2, 1669, 1519, 2070) X(5, 4, 9, 2, 3, 1148, 1079, 1469) \
     X(6, 4, 4, 2, 4, 694, 666, 874) X(7, 4, 2, 4, 2, 601, 535, 637) X(8, 1, 2, 1, 2, 950, 789, 1055) \
-    X(9, 5, 4, 1, 4, 831, 789, 1089) X(10, 4, 6, 2, 2, 900, 819, 1116) X(11, 2, 5, 2, 1, 673, 633, 861)
+    X(9, 5, 4, 1, 4, 831, 789, 1089) X(10, 4, 6, 2, 2, 900, 819, 1116) X(11, 2, 5, 2, 1, 673, 633, 861) \
+    X(12, 1, 8, 1, 8, 853, 637, 871)
 
 NK_HD int64_t gemm_slice_floats(int MT, int NT, int WN) { return (int64_t)MT * NT * 1024 + (int64_t)MT * WN * 32; }
 
@@ -690,12 +692,11 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
     const int pex0 = 3 + 6 * p.Lx;          // width of gamma(x) inside a skip layer's input
     if (p.no_dirs) {
         // no view directions: the only product above the trunk is the output layer's, rows 0..3 of dOut
-        // against h_{D-1}.  It runs as the feature-layer product below with that layer's dZ segment (all
-        // zeros here) switched off in the reduction, so no further tile shape is compiled for it.
+        // against h_{D-1}
         GemmDst d[2][2] = {};
-        d[1][0] = gemm_dst(lalpha.w_off, lalpha.in_dim, 0, 4, NK_COL_IDENT, 0, W, 0);
-        d[1][0].row_tiled = 0;              // the dOut tile keeps its rows in ascending order
-        queue_gemm(q, dz(2), W, dz(0), 32, act(2 + D - 1), W, nullptr, 0, G, grad, d, -1, lalpha.b_off);
+        d[0][0] = gemm_dst(lalpha.w_off, lalpha.in_dim, 0, 4, NK_COL_IDENT, 0, W, 0);
+        d[0][0].row_tiled = 0;              // the dOut tile keeps its rows in ascending order
+        queue_gemm(q, dz(0), 32, nullptr, 0, act(2 + D - 1), W, nullptr, 0, G, grad, d, lalpha.b_off, -1);
     } else {
     {   // rgb: rows 0..2 of dOut against g
         GemmDst d[2][2] = {};

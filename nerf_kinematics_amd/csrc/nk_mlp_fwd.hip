@@ -158,7 +158,8 @@ __global__ __launch_bounds__(64) void k_pack_weights(NkPlan p, const float* __re
         const int b = blk - p.fwd_blocks;
         // transposed stream order: RGB, VIEWS, FEAT, trunk D-1 .. 1
         int order[NK_MAX_LAYERS], n = 0;
-        order[n++] = p.D + 3; order[n++] = p.D + 2; order[n++] = p.D + 1;
+        if (!p.no_dirs) { order[n++] = p.D + 3; order[n++] = p.D + 2; }
+        order[n++] = p.D + 1;
         for (int i = p.D - 1; i >= 1; --i) order[n++] = i;
         int k = 0;
         while (k + 1 < n && b >= p.layer[order[k + 1]].bwd_block0) ++k;

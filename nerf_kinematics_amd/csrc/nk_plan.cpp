@@ -134,8 +134,10 @@ int nk_build_plan(const nk_arch* a, NkPlan* p) {
         l.bwd_tiles = tiles; l.bwd_nk = nk; l.bwd_act_col = act_col; l.bwd_block0 = blk;
         blk += tiles * nk;
     };
-    add_bwd(L_RGB, WD / 32, 1, 0);
-    add_bwd(L_VIEWS, W / 32, WD / 16, 0);
+    if (!p->no_dirs) {      // (without view directions the chain starts at the stage below, on dOut alone)
+        add_bwd(L_RGB, WD / 32, 1, 0);
+        add_bwd(L_VIEWS, W / 32, WD / 16, 0);
+    }
     add_bwd(L_FEAT, W / 32, W / 16 + 1, 0);
     for (int i = D - 1; i >= 1; --i)
         add_bwd(i, W / 32, W / 16, (a->skip >= 0 && i == a->skip + 1) ? in_xyz : 0);

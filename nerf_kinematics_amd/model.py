@@ -10,7 +10,7 @@ Two nerf-pytorch lineages are supported (``lineage``):
                key names of its checkpoints (``layer1``, ``layers_xyz.N``, ``layers_dir.0``,
                ``fc_alpha``, ``fc_rgb``, ``fc_feat``).
 
-``use_viewdirs=False`` (``models.*.use_viewdirs`` of the same file, line 39) drops the direction
+``use_viewdirs=False`` (``models.*.use_viewdirs`` of the same file, lines 30 and 42) drops the direction
 branch of either lineage: the trunk is followed by ONE linear layer with four rows
 (rgb_raw, sigma_raw), ``output_linear`` / ``fc_out`` in the public nerf-pytorch sources.
 

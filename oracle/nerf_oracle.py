@@ -195,7 +195,7 @@ class Arch:
     ``views_linears.0`` on cat[feat, gamma(d)] + ReLU; ``rgb_linear``.  Parameter order:
     pts_linears, views_linears, feature_linear, alpha_linear, rgb_linear.
 
-    ``use_viewdirs=False`` (``models.*.use_viewdirs``, config.yml:39, and ``nerf.use_viewdirs``, :55):
+    ``use_viewdirs=False`` (``models.*.use_viewdirs``, config.yml:30,42, and ``nerf.use_viewdirs``, :55):
     either lineage without its direction branch, the trunk followed by one four-row linear layer
     (rgb_raw, sigma_raw) called ``fc_out`` / ``output_linear`` in the public nerf-pytorch sources;
     ray-batch rows then have 8 columns.  Parity unpinned: the reference ships no such network.

@@ -1,5 +1,5 @@
 """GPU parity tests of networks WITHOUT view directions (``use_viewdirs: False``,
-/root/reference/trained_models/nerf-pytorch/lego-lowres3/config.yml:39,55 are the keys): either lineage
+/root/reference/trained_models/nerf-pytorch/lego-lowres3/config.yml:30,42,55 are the keys): either lineage
 with the trunk followed by one four-row linear layer (rgb_raw, sigma_raw), ray rows of 8 columns.
 
 Parity unpinned: the reference ships no such network; the oracle follows the public nerf-pytorch
@@ -92,10 +92,13 @@ def test_parameter_layout(nk):
         assert nklib.check(L.nk_num_params(arch.to_c())) == arch.num_params() == oarch(arch).num_params()
         if n is not None:
             assert arch.num_params() == n
-        # the bf16 fragment image keeps the stream sequence of the networks with a direction branch
+        # the bf16 fragment image: the forward streams keep the stage sequence of a network with a direction
+        # branch, the transposed stream loses the two stages of that branch (WD/32 + W/32 * WD/16 blocks)
         with_dirs = nk.Arch(arch.depth, arch.width, arch.skip, arch.dir_width, arch.n_freq_xyz, arch.n_freq_dir,
                             arch.relu_first, arch.relu_feat, arch.lineage)
-        assert nklib.check(L.nk_packed_bytes(arch.to_c())) == nklib.check(L.nk_packed_bytes(with_dirs.to_c()))
+        W, WD = arch.width, arch.dir_width
+        assert nklib.check(L.nk_packed_bytes(with_dirs.to_c())) - nklib.check(L.nk_packed_bytes(arch.to_c())) == \
+            (WD // 32 + (W // 32) * (WD // 16)) * 1024
 
 
 @pytest.mark.parametrize("which,R,n", [("flexible", 20, 64), ("flexible_L6", 7, 33), ("run_nerf", 12, 192)])

@@ -80,7 +80,7 @@ def test_experiment_keys_default_off_and_reach_the_render_options(golden_dir):
 
 
 def test_use_viewdirs_false_builds_networks_without_the_direction_branch(golden_dir, tmp_path):
-    """nerf.use_viewdirs and models.*.use_viewdirs (config.yml:39,55 of the reference's files) all False:
+    """nerf.use_viewdirs and models.*.use_viewdirs (config.yml:30,42,55 of the reference's files) all False:
     either lineage ends in one four-row layer; a checkpoint written for such a pair has those key names,
     loads into a plain torch module tree of the public model class, and round-trips bit-exactly."""
     off = {"nerf": {"use_viewdirs": False}, "models": {"coarse": {"use_viewdirs": False}, "fine": {"use_viewdirs": False}}}
