@@ -124,6 +124,7 @@ typedef struct nk_render_out {
     float *rgb_coarse, *disp_coarse, *acc_coarse, *depth_coarse;
 } nk_render_out;
 
+/* Version of this header: the structs above changed layout at 101 (nk_render_opts) and 102 (nk_arch). */
 int nk_version(void);
 const char* nk_last_error(void);
 

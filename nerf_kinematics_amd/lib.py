@@ -25,6 +25,9 @@ ACT_FORMATS = {"bf16": 0, "fp8": 1, "fp8bf8": 2}
 STREAM_STRATIFIED, STREAM_PDF, STREAM_NOISE_COARSE, STREAM_NOISE_FINE, STREAM_PIXELS = 0, 1, 2, 3, 4
 
 
+ABI_VERSION = 102          # nk_version() of the library these ctypes declarations describe
+
+
 class NkArch(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("depth", "width", "skip", "dir_width", "n_freq_xyz", "n_freq_dir",
                                          "relu_first", "relu_feat", "lineage", "no_viewdirs")]
@@ -105,6 +108,12 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    # the structs above mirror include/nerf_kinematics.h of ONE library version (nk_arch grew a field in
+    # 102); a library built from other sources would read them wrongly.  NK_LIB (a developer comparing two
+    # builds) takes the responsibility itself.
+    if lib.nk_version() != ABI_VERSION and "NK_LIB" not in os.environ:
+        raise ImportError(f"{LIB_PATH} reports version {lib.nk_version()}, these bindings are for {ABI_VERSION}: "
+                          f"rebuild it with `make -C {os.path.join(_HERE, 'csrc')}`")
     _lib = lib
     return lib
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in the header but not exported"
         assert s in lib.SIGNATURES, f"{s} has no ctypes prototype"
-    assert L.nk_version() >= 100
+    assert L.nk_version() == lib.ABI_VERSION == 102
 
 
 def test_parameter_counts_match_the_reference_checkpoints():
@@ -36,6 +36,10 @@ def test_parameter_counts_match_the_reference_checkpoints():
     # fragment streams: forward 1 KiB per (tile, k-step) + one bias block per tile, then transposed,
     # then the forward stream again in the operand order of the 16x16x32 inference kernel
     assert L.nk_packed_bytes(nk.ARCH_RUN_NERF.to_c()) == (1262 + 1100 + 1262) * 1024
+    # without view directions: trunk + one four-row layer; the transposed stream loses the direction branch
+    novd = nk.Arch(use_viewdirs=False)
+    assert L.nk_num_params(novd.to_c()) == novd.num_params() == 595844 - (283 * 128 + 128) - (256 * 256 + 256) - 257 - 387 + 4 * 257
+    assert L.nk_packed_bytes(novd.to_c()) == (1262 + 1100 - 4 - 8 * 8 + 1262) * 1024
 
 
 def test_unsupported_shapes_are_rejected_with_a_message():
