@@ -161,6 +161,52 @@ def test_render_rays_gradients(nk, dev, which):
     check_grads(arch_f, f.flat.grad, ffo.grad, 5e-2)
 
 
+def test_large_batch_gradients(nk, dev):
+    """8x256 pair without view directions after 200 training iterations, one ragged batch of 5 507 rays
+    (1 057 344 fine points): above the size where the weight-gradient products are launched network by
+    network in about 256 K-slices each, so the output layer's own product (1 x 8 tiles, dOut against
+    h_{D-1}) runs with long slices and a short last one.  Oracle evaluated in pieces of 1 024 rays."""
+    from nerf_kinematics_amd.datasets import RaySampler, teacher_scene
+    from nerf_kinematics_amd.trainer import Trainer, TrainOpts
+    from nerf_kinematics_amd import lib as nklib
+    arch = archs(nk)["run_nerf"]
+    R = 5507
+    assert R * 192 > nklib.PAIR_GEMM_MAX_POINTS
+    scene = teacher_scene(None, 8, 0, 100, dev)
+    tr = Trainer(arch, arch, TrainOpts(num_coarse=64, num_fine=128, num_random_rays=1024, perturb=True,
+                                       radiance_field_noise_std=0.2, lr=5e-4, seed=42), dev)
+    smp = RaySampler(scene, 1024, seed=3)
+    l0 = float(tr.step(*smp.next(0)))
+    for i in range(1, 200):
+        l1 = float(tr.step(*smp.next(i)))
+    assert l1 < 0.7 * l0                        # the pair trains
+    rb, target = RaySampler(scene, R, seed=8).next(200)
+    rb8 = rb[:, :8].contiguous()               # the rows the reference builds for such networks
+    fc, ff = tr.coarse.flat.detach().clone(), tr.fine.flat.detach().clone()
+    kw = dict(perturb=True, radiance_field_noise_std=0.2, seed=77)
+    c, f = nk.NeRFModel(arch, fc.clone()), nk.NeRFModel(arch, ff.clone())
+    c.flat.requires_grad_(True); f.flat.requires_grad_(True)
+    out = nk.render_rays(rb8, c, f, num_coarse=64, num_fine=128, **kw)
+    loss = ((out[3] - target) ** 2).mean() + ((out[0] - target) ** 2).mean()
+    loss.backward()
+    fco, ffo = fc.cpu().requires_grad_(True), ff.cpu().requires_grad_(True)
+    rbc, tc, total = rb8.cpu(), target.cpu(), 0.0
+    for s in range(0, R, 1024):
+        co = O.NeRFNet.from_flat(oarch(arch), fco, emulate_bf16=True)
+        fo = O.NeRFNet.from_flat(oarch(arch), ffo, emulate_bf16=True)
+        o = O.render_rays(rbc[s:s + 1024], co, fo, O.RenderOpts(64, 128, **kw), ray_offset=s)
+        t = tc[s:s + 1024]
+        part = (((o["rgb_coarse"] - t) ** 2).sum() + ((o["rgb_fine"] - t) ** 2).sum()) / (3 * R)
+        part.backward()
+        total += float(part.detach())
+    print(f"loss: HIP {float(loss.detach()):.6f}, oracle {total:.6f}; whole-gradient relative L2 coarse "
+          f"{float((c.flat.grad.cpu() - fco.grad).norm() / fco.grad.norm()):.4f}, fine "
+          f"{float((f.flat.grad.cpu() - ffo.grad).norm() / ffo.grad.norm()):.4f}")
+    assert abs(float(loss.detach()) - total) < 2e-3 * total + 1e-5
+    check_grads(arch, c.flat.grad, fco.grad, 5e-2)
+    check_grads(arch, f.flat.grad, ffo.grad, 5e-2)
+
+
 def test_columns_8_to_10_are_never_read(nk, dev):
     """8-column rows and 11-column rows with NaN in the direction columns give the same bits, in
     inference and in training; a network WITH a direction branch refuses 8-column rows."""
