@@ -12,7 +12,13 @@ dev = torch.device("cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 scene = teacher_scene(None, 4, 0, 100, dev)
 bad = 0
-for arch, name in ((nk.ARCH_RUN_NERF, "8x256"), (nk.ARCH_LEGO_CKPT, "4x128")):
+A = nk.Arch
+shapes = ((nk.ARCH_RUN_NERF, "8x256"), (nk.ARCH_LEGO_CKPT, "4x128"),
+          (A(8, 256, 4, 128, 10, 4, True, False, "run_nerf", False), "8x256 no viewdirs"),
+          (A(4, 128, -1, 64, 10, 4, False, True, "flexible", False), "4x128 no viewdirs"))
+if len(sys.argv) > 2:       # a substring selects shapes
+    shapes = tuple(s for s in shapes if sys.argv[2] in s[1])
+for arch, name in shapes:
     for R in (16384, 5507, 1024, 37):
         rb, tgt = RaySampler(scene, R, seed=5).next(0)
         for fmt in ("bf16", "fp8", "fp8bf8"):
