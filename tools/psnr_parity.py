@@ -19,13 +19,17 @@ ap.add_argument("--every", type=int, default=100)
 ap.add_argument("--seed", type=int, default=42)
 ap.add_argument("--lr", type=float, default=5e-3)
 ap.add_argument("--act-format", default="bf16", choices=("bf16", "fp8", "fp8bf8"), help="saved-tensor format of the HIP run")
+ap.add_argument("--no-viewdirs", action="store_true", help="networks without the direction branch (use_viewdirs: False)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 Nc, Nf = 32, 32
 scene = datasets.teacher_scene(None, 12, 3, a.res, dev, num_coarse=64, num_fine=64)
 arch = nk.ARCH_LEGO_CKPT
+if a.no_viewdirs:
+    arch = nk.Arch(arch.depth, arch.width, arch.skip, arch.dir_width, arch.n_freq_xyz, arch.n_freq_dir, arch.relu_first,
+                   arch.relu_feat, arch.lineage, use_viewdirs=False)
 oa = O.Arch(arch.depth, arch.width, arch.skip, arch.dir_width, arch.n_freq_xyz, arch.n_freq_dir, arch.relu_first,
-            arch.relu_feat, arch.lineage)
+            arch.relu_feat, arch.lineage, arch.use_viewdirs)
 opts = TrainOpts(num_coarse=Nc, num_fine=Nf, num_random_rays=a.rays, perturb=True, radiance_field_noise_std=0.2,
                  lr=a.lr, seed=a.seed, act_format=a.act_format)
 tr = Trainer(arch, arch, opts, dev)
