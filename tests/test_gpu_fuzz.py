@@ -1,6 +1,7 @@
 """Randomised parity sweep as a test: tools/fuzz_parity.py draws network shapes (both lineages, with
 and without view directions, depths 2..8, any skip position, encoding lengths 1..10 / 1..4), sample
-counts (2..96 coarse, 0..160 fine), ray counts (1, 2, 31, 33, ...), NDC or not and the render flags,
+counts (2..96 coarse, 0..160 fine), ray counts (1, 2, 31, 33, ...), NDC or not, the render flags and
+the saved-tensor format,
 and compares the maps and both gradients of render_rays with the bf16-emulating oracle (maps 2e-2
 absolute, whole-gradient relative L2 5e-2).  25 cases here; profiles hold two sweeps of 100."""
 import os

@@ -1,7 +1,7 @@
 """Randomised parity sweep of render_rays against the oracle (dev tool): random network shapes (both
 lineages, with and without view directions, depth, skip, encoding lengths), sample counts, ray
-counts and flags; compares the six maps of an inference call and, for training calls, loss and the
-gradient of both networks with the bf16-emulating oracle.
+counts, flags and saved-tensor formats; compares the rgb and opacity maps of a training call and the
+gradient of both networks with the bf16-emulating oracle (which emulates the 8-bit formats too).
 
     python tools/fuzz_parity.py [cases] [seed]"""
 import math, os, sys
@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import nerf_kinematics_amd as nk
+from nerf_kinematics_amd import render as render_mod
 from oracle import nerf_oracle as O
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -42,6 +43,7 @@ for case in range(cases):
     kw = dict(perturb=bool(rng.integers(0, 2)), lindisp=bool(rng.random() < 0.3) and not ndc,
               radiance_field_noise_std=float(rng.choice([0.0, 0.2, 1.0])), white_background=bool(rng.random() < 0.3),
               seed=int(rng.integers(0, 2 ** 31)))
+    fmt = str(rng.choice(["bf16", "bf16", "fp8", "fp8bf8"]))
     H = Wd = 24
     focal = 0.5 * Wd / math.tan(0.5 * 0.6911112070083618)
     g = torch.Generator().manual_seed(case)
@@ -73,19 +75,20 @@ for case in range(cases):
     target = torch.rand(R, 3, generator=g)
     tag = (f"case {case}: coarse {arch_c.depth}x{arch_c.width} {arch_c.lineage} skip {arch_c.skip} L {arch_c.n_freq_xyz}/{arch_c.n_freq_dir} "
            f"dirs {int(arch_c.use_viewdirs)} | fine {arch_f.depth}x{arch_f.width} {arch_f.lineage} skip {arch_f.skip} dirs {int(arch_f.use_viewdirs)} "
-           f"| R {R} Nc {Nc} Nf {Nf} cols {rb.shape[1]} ndc {int(ndc)} {kw}")
+           f"| R {R} Nc {Nc} Nf {Nf} cols {rb.shape[1]} ndc {int(ndc)} {fmt} {kw}")
     try:
         c = nk.NeRFModel(arch_c, fc.to(dev)); f = nk.NeRFModel(arch_f, ff.to(dev)) if Nf > 0 else None
         c.flat.requires_grad_(True)
         if f is not None:
             f.flat.requires_grad_(True)
-        out = nk.render_rays(rb.to(dev), c, f, num_coarse=Nc, num_fine=Nf, **kw)
+        out = nk.render_rays(rb.to(dev), c, f, num_coarse=Nc, num_fine=Nf, act_format=fmt, **kw)
         tg = target.to(dev)
         loss = ((out[3] - tg) ** 2).mean() + (((out[0] - tg) ** 2).mean() if Nf > 0 else 0.0)
         loss.backward()
         fco, ffo = fc.clone().requires_grad_(True), ff.clone().requires_grad_(True)
-        co = O.NeRFNet.from_flat(oarch(arch_c), fco, emulate_bf16=True)
-        fo = O.NeRFNet.from_flat(oarch(arch_f), ffo, emulate_bf16=True) if Nf > 0 else None
+        S = render_mod.dz_scale(R)
+        co = O.NeRFNet.from_flat(oarch(arch_c), fco, emulate_bf16=True, act_format=fmt, dz_scale=S)
+        fo = O.NeRFNet.from_flat(oarch(arch_f), ffo, emulate_bf16=True, act_format=fmt, dz_scale=S) if Nf > 0 else None
         ref = O.render_rays(rb, co, fo, O.RenderOpts(Nc, Nf, **kw))
         lref = ((ref["rgb_coarse"] - target) ** 2).mean() + (((ref["rgb_fine"] - target) ** 2).mean() if Nf > 0 else 0.0)
         lref.backward()
@@ -97,7 +100,8 @@ for case in range(cases):
         gc = float((c.flat.grad.cpu() - fco.grad).norm() / (fco.grad.norm() + 1e-20))
         gf = float((f.flat.grad.cpu() - ffo.grad).norm() / (ffo.grad.norm() + 1e-20)) if Nf > 0 else 0.0
         gnorm = float(fco.grad.norm())
-        ok = max(errs.values()) < 2e-2 and (gc < 5e-2 or gnorm < 1e-7) and (gf < 5e-2 or float(ffo.grad.norm()) < 1e-7) \
+        gtol = 5e-2          # whole-gradient relative L2 (the per-tensor bounds of the tests are 5e-2 / 1e-1)
+        ok = max(errs.values()) < 2e-2 and (gc < gtol or gnorm < 1e-7) and (gf < gtol or float(ffo.grad.norm()) < 1e-7) \
             and torch.isfinite(c.flat.grad).all()
         print(("ok   " if ok else "FAIL ") + tag + f" -> max map err {max(errs.values()):.2e}, grad rel coarse {gc:.3e} fine {gf:.3e} (|g| {gnorm:.2e})", flush=True)
         bad += 0 if ok else 1
