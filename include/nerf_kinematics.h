@@ -48,6 +48,12 @@ enum { NK_LINEAGE_RUN_NERF = 0, NK_LINEAGE_FLEXIBLE = 1 };
  * dir_width and n_freq_dir are then ignored apart from the width pairing the kernels are
  * compiled for, and columns 8..10 of a ray-batch row are never read.                          */
 
+/* Variants of the positional encoding (include_input_xyz / _dir, log_sampling_xyz / _dir of
+ * config.yml:21-24; both reference files set all four True = no bit set):
+ *   NK_ENC_NO_INPUT_*  gamma() does not start with the raw 3-vector (input width 6 L instead of 3 + 6 L)
+ *   NK_ENC_LINEAR_*    frequencies torch.linspace(1, 2^(L-1), L) instead of 2^0 .. 2^(L-1)             */
+enum { NK_ENC_NO_INPUT_XYZ = 1, NK_ENC_NO_INPUT_DIR = 2, NK_ENC_LINEAR_XYZ = 4, NK_ENC_LINEAR_DIR = 8 };
+
 /* models.coarse / models.fine of config.yml:18-42 */
 typedef struct nk_arch {
     int32_t depth;       /* trunk layers D, first layer included            (8 | 4)   */
@@ -60,6 +66,7 @@ typedef struct nk_arch {
     int32_t relu_feat;   /* ReLU after the feature layer                               */
     int32_t lineage;     /* NK_LINEAGE_*                                               */
     int32_t no_viewdirs; /* 1: no view-direction branch (use_viewdirs: False)                  */
+    int32_t enc_flags;   /* NK_ENC_* bits; 0 = include_input_*: True, log_sampling_*: True     */
 } nk_arch;
 
 /* Per-iteration scalars of a training step kept in DEVICE memory, so that a step whose launches
@@ -124,7 +131,7 @@ typedef struct nk_render_out {
     float *rgb_coarse, *disp_coarse, *acc_coarse, *depth_coarse;
 } nk_render_out;
 
-/* Version of this header: the structs above changed layout at 101 (nk_render_opts) and 102 (nk_arch). */
+/* Version of this header: the structs above changed layout at 101 (nk_render_opts), 102 and 103 (nk_arch). */
 int nk_version(void);
 const char* nk_last_error(void);
 

@@ -61,8 +61,9 @@ def arch_for_state_dict(model_cfg: dict, sd: Dict[str, torch.Tensor]) -> Arch:
     if first not in sd:
         raise ValueError(f"state dict has no {first}; keys: {list(sd)[:4]}...")
     W, in_xyz = sd[first].shape
-    if (in_xyz - 3) % 6:
-        raise ValueError(f"{first}: input width {in_xyz} is not 3 + 6 L")
+    raw_x, raw_d = (3 if arch.include_input_xyz else 0), (3 if arch.include_input_dir else 0)
+    if (in_xyz - raw_x) % 6:
+        raise ValueError(f"{first}: input width {in_xyz} is not {raw_x} + 6 L")
     if arch.use_viewdirs:
         dirs = "layers_dir.0.weight" if arch.lineage == "flexible" else "views_linears.0.weight"
         WD, in_views = sd[dirs].shape
@@ -74,8 +75,9 @@ def arch_for_state_dict(model_cfg: dict, sd: Dict[str, torch.Tensor]) -> Arch:
         for i in range(arch.depth):
             if sd[f"pts_linears.{i}.weight"].shape[1] == W + in_xyz:
                 skip = i - 1
-    return Arch(arch.depth, int(W), skip, int(WD), (int(in_xyz) - 3) // 6, (int(in_views) - int(W) - 3) // 6,
-                arch.relu_first, arch.relu_feat, arch.lineage, arch.use_viewdirs)
+    return Arch(arch.depth, int(W), skip, int(WD), (int(in_xyz) - raw_x) // 6, (int(in_views) - int(W) - raw_d) // 6,
+                arch.relu_first, arch.relu_feat, arch.lineage, arch.use_viewdirs, arch.include_input_xyz,
+                arch.include_input_dir, arch.log_sampling_xyz, arch.log_sampling_dir)
 
 
 @dataclass

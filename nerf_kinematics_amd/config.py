@@ -69,9 +69,6 @@ def validate(cfg: dict) -> dict:
             if which == "coarse":
                 raise ConfigError("models.coarse is required")
             continue
-        for key in ("include_input_xyz", "include_input_dir", "log_sampling_xyz", "log_sampling_dir"):
-            if not m.get(key, True):
-                raise ConfigError(f"models.{which}.{key}: false is not supported")
         # the ray rows carry view directions exactly when the networks take them (in the reference a
         # mismatch is a shape error at the first layer of the direction branch)
         if bool(m.get("use_viewdirs", True)) != vd:

@@ -75,6 +75,18 @@ NK_HD int nk_pe_dir_col(int q /* 8*s + j */, int h, int L) {
     return -1;
 }
 
+// Column of an encoding WITHOUT the raw input (NK_ENC_NO_INPUT_*) for a column of the full one: the
+// three raw coordinates have no column, every sin / cos moves down by three.
+NK_HD int nk_enc_col(int col, int with_input) { return (with_input || col < 0) ? col : (col < 3 ? -1 : col - 3); }
+
+// Frequency l of an encoding of L frequencies: 2^l, or element l of torch.linspace(1, 2^(L-1), L) in
+// float32 (forward from the start for the first half, backward from the end for the second, as torch
+// computes it; `step` and `end` come from the plan).  Slots beyond L carry no weight: any finite value.
+NK_HD float nk_enc_freq(int linear, float step, float end, int L, int l, float pow2) {
+    if (!linear) return pow2;
+    return (l < L / 2) ? 1.0f + step * (float)l : end - step * (float)(L - 1 - l);
+}
+
 // ---- network plan ---------------------------------------------------------------------------
 // Layers in forward order: trunk 0..D-1, then ALPHA, FEAT, VIEWS, RGB.  A network without view
 // directions (NkPlan::no_dirs) keeps the sequence: its output layer sits in ALPHA's place (rows
@@ -103,6 +115,9 @@ struct NkLayer {
 
 struct NkPlan {
     int D, W, WD, skip, Lx, Ld, relu_first, relu_feat, lineage, no_dirs;
+    int inc_x, inc_d;       // the encodings start with the raw 3-vector (include_input_*)
+    int lin_x, lin_d;       // linearly spaced frequencies (log_sampling_*: False) ...
+    float step_x, end_x, step_d, end_d;     // ... torch.linspace(1, end, L): its step and last element
     int NL;                 // D + 4
     NkLayer layer[NK_MAX_LAYERS];
     int fwd_blocks, bwd_blocks;   // stream lengths in 1-KiB blocks

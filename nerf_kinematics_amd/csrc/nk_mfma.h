@@ -38,12 +38,12 @@ NK_D void nk_fp8_saturate() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
 
 // gamma(x) as 4 B-operand fragments (k-slots per nk_pe_xyz_col); p8 (optional): the same 32 slots
 // as e4m3 bytes, dwords 2s, 2s+1 = k-step s
-NK_D void pe_xyz_frags(float px, float py, float pz, int h, Frag (&f)[4], uint32_t* p8 = nullptr) {
+NK_D void pe_xyz_frags(const NkPlan& p, float px, float py, float pz, int h, Frag (&f)[4], uint32_t* p8 = nullptr) {
     float v[32];
     const float base = h ? 32.0f : 1.0f;
 #pragma unroll
     for (int fi = 0; fi < 5; ++fi) {
-        const float sc = base * (float)(1 << fi);
+        const float sc = nk_enc_freq(p.lin_x, p.step_x, p.end_x, p.Lx, 5 * h + fi, base * (float)(1 << fi));
         sincos_rev(px * sc, v[6 * fi + 0], v[6 * fi + 3]);
         sincos_rev(py * sc, v[6 * fi + 1], v[6 * fi + 4]);
         sincos_rev(pz * sc, v[6 * fi + 2], v[6 * fi + 5]);
@@ -61,12 +61,12 @@ NK_D void pe_xyz_frags(float px, float py, float pz, int h, Frag (&f)[4], uint32
 }
 
 // gamma(d) as 2 fragments (k-slots per nk_pe_dir_col); p8 (optional): e4m3 bytes, dwords 2s, 2s+1 = k-step s
-NK_D void pe_dir_frags(float dx, float dy, float dz, int h, Frag (&f)[2], uint32_t* p8 = nullptr) {
+NK_D void pe_dir_frags(const NkPlan& p, float dx, float dy, float dz, int h, Frag (&f)[2], uint32_t* p8 = nullptr) {
     float v[16];
     const float base = h ? 4.0f : 1.0f;
 #pragma unroll
     for (int fi = 0; fi < 2; ++fi) {
-        const float sc = base * (float)(1 << fi);
+        const float sc = nk_enc_freq(p.lin_d, p.step_d, p.end_d, p.Ld, 2 * h + fi, base * (float)(1 << fi));
         sincos_rev(dx * sc, v[6 * fi + 0], v[6 * fi + 3]);
         sincos_rev(dy * sc, v[6 * fi + 1], v[6 * fi + 4]);
         sincos_rev(dz * sc, v[6 * fi + 2], v[6 * fi + 5]);

@@ -40,6 +40,7 @@ struct GemmDst {
     int w_off, ld;                          // destination matrix origin and leading dimension
     int row_first, row_count, row_dst0;     // segment rows [row_first, +row_count) -> matrix rows row_dst0..
     int colmode, col_base, col_count, nfreq;
+    int with_input;                         // encodings: the reference matrix has columns for the raw 3-vector
     int row_tiled, col_tiled;               // rows / identity columns arrive in nk_tile_feature() order
 };
 
@@ -215,7 +216,8 @@ NK_D int64_t gemm_dst_index(const GemmOut& a, int mt, int nt, int m_in_tile, int
         const int s = n >> 4, hh = (n >> 3) & 1, jj = n & 7;
         const int cc = d.colmode == NK_COL_PEX ? (s < 4 ? nk_pe_xyz_col(8 * s + jj, hh, d.nfreq) : -1)
                                                : (s < 2 ? nk_pe_dir_col(8 * s + jj, hh, d.nfreq) : -1);
-        dcol = cc >= 0 ? d.col_base + cc : -1;
+        const int ec = nk_enc_col(cc, d.with_input);
+        dcol = ec >= 0 ? d.col_base + ec : -1;
     }
     if (dcol < 0) return -1;
     const int mr = 32 * (mt - (sa ? a.MA0 : 0)) + m_in_tile - d.row_first;
@@ -460,8 +462,9 @@ __global__ __launch_bounds__(256) void k_dw_reduce(ReduceBatch batch) {
 }
 
 static GemmDst gemm_dst(int w_off, int ld, int row_first, int row_count, int colmode, int col_base, int col_count,
-                        int nfreq) {
+                        int nfreq, int with_input = 1) {
     GemmDst d;
+    d.with_input = with_input;
     d.enabled = 1; d.w_off = w_off; d.ld = ld; d.row_first = row_first; d.row_count = row_count; d.row_dst0 = 0;
     d.colmode = colmode; d.col_base = col_base; d.col_count = col_count; d.nfreq = nfreq;
     d.row_tiled = 1; d.col_tiled = 1;       // dZ / activation tiles as the chain kernels store them
@@ -689,7 +692,7 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
     const NkLayer& lviews = p.layer[D + 2];
     const NkLayer& lfeat = p.layer[D + 1];
     const NkLayer& lalpha = p.layer[D];
-    const int pex0 = 3 + 6 * p.Lx;          // width of gamma(x) inside a skip layer's input
+    const int pex0 = 3 * p.inc_x + 6 * p.Lx;          // width of gamma(x) inside a skip layer's input
     if (p.no_dirs) {
         // no view directions: the only product above the trunk is the output layer's, rows 0..3 of dOut
         // against h_{D-1}
@@ -707,7 +710,7 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
     {   // views: dZ_views against cat[feat, gamma(d)]
         GemmDst d[2][2] = {};
         d[0][0] = gemm_dst(lviews.w_off, lviews.in_dim, 0, WD, NK_COL_IDENT, 0, W, 0);
-        d[0][1] = gemm_dst(lviews.w_off, lviews.in_dim, 0, WD, NK_COL_PED, W, 32, p.Ld);
+        d[0][1] = gemm_dst(lviews.w_off, lviews.in_dim, 0, WD, NK_COL_PED, W, 32, p.Ld, p.inc_d);
         queue_gemm(q, dz(1), WD, nullptr, 0, act(2 + D), W, act(1), 32, G, grad, d, lviews.b_off, -1);
     }
     {   // feature layer and alpha: dZ_feat and row 3 of dOut, side by side, against h_{D-1} (read once)
@@ -723,11 +726,11 @@ static int queue_network_gemms(GemmQueue& q, const NkBwdJob& j) {
         const char* dzl = dz(3 + D - 1 - L);
         GemmDst d[2][2] = {};
         if (L == 0) {
-            d[0][0] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_PEX, 0, 64, p.Lx);
+            d[0][0] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_PEX, 0, 64, p.Lx, p.inc_x);
             queue_gemm(q, dzl, W, nullptr, 0, act(0), 64, nullptr, 0, G, grad, d, l.b_off, -1);
         } else if (p.skip >= 0 && L == p.skip + 1) {
             d[0][0] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_IDENT, pex0, W, 0);
-            d[0][1] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_PEX, 0, 64, p.Lx);
+            d[0][1] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_PEX, 0, 64, p.Lx, p.inc_x);
             queue_gemm(q, dzl, W, nullptr, 0, act(2 + L - 1), W, act(0), 64, G, grad, d, l.b_off, -1);
         } else {
             d[0][0] = gemm_dst(l.w_off, l.in_dim, 0, W, NK_COL_IDENT, 0, W, 0);

@@ -30,9 +30,9 @@ __device__ float fwd_weight_elem(const NkPlan& p, const float* __restrict__ prm,
     if (l.seg_type[seg] == NK_SEG_ACT) {
         col = 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
     } else if (l.seg_type[seg] == NK_SEG_PEX) {
-        col = nk_pe_xyz_col(8 * s + j, h, p.Lx);
+        col = nk_enc_col(nk_pe_xyz_col(8 * s + j, h, p.Lx), p.inc_x);
     } else {
-        col = nk_pe_dir_col(8 * s + j, h, p.Ld);
+        col = nk_enc_col(nk_pe_dir_col(8 * s + j, h, p.Ld), p.inc_d);
     }
     if (col < 0) return 0.0f;
     col += l.seg_col[seg];
@@ -93,8 +93,8 @@ __device__ float fwd16_weight_elem(const NkPlan& p, const float* __restrict__ pr
     while (seg < l.n_seg - 1 && s >= l.seg_steps[seg] / 2) { s -= l.seg_steps[seg] / 2; ++seg; }
     int col;
     if (l.seg_type[seg] == NK_SEG_ACT) col = 32 * s + 16 * (j >> 2) + 4 * kq + (j & 3);
-    else if (l.seg_type[seg] == NK_SEG_PEX) col = nk16_pe_xyz_col(32 * s + 8 * kq + j, p.Lx);
-    else col = nk16_pe_dir_col(32 * s + 8 * kq + j, p.Ld);
+    else if (l.seg_type[seg] == NK_SEG_PEX) col = nk_enc_col(nk16_pe_xyz_col(32 * s + 8 * kq + j, p.Lx), p.inc_x);
+    else col = nk_enc_col(nk16_pe_dir_col(32 * s + 8 * kq + j, p.Ld), p.inc_d);
     if (col < 0) return 0.0f;
     col += l.seg_col[seg];
     if (col >= l.in_dim) return 0.0f;

@@ -33,7 +33,7 @@ int nk_waves_per_wg(int backward) {
 }
 
 extern "C" const char* nk_last_error(void) { return g_err; }
-extern "C" int nk_version(void) { return 102; }
+extern "C" int nk_version(void) { return 103; }
 
 int nk_build_plan(const nk_arch* a, NkPlan* p) {
     if (!a || !p) NK_FAIL(NK_ERR_ARG, "nk_build_plan: null argument");
@@ -54,7 +54,16 @@ int nk_build_plan(const nk_arch* a, NkPlan* p) {
     p->relu_first = a->relu_first != 0; p->relu_feat = a->relu_feat != 0; p->lineage = a->lineage;
     p->no_dirs = a->no_viewdirs != 0;
     p->NL = D + 4;
-    const int in_xyz = 3 + 6 * p->Lx, in_dir = 3 + 6 * p->Ld;
+    if (a->enc_flags & ~(NK_ENC_NO_INPUT_XYZ | NK_ENC_NO_INPUT_DIR | NK_ENC_LINEAR_XYZ | NK_ENC_LINEAR_DIR))
+        NK_FAIL(NK_ERR_ARG, "unknown enc_flags 0x%x", a->enc_flags);
+    p->inc_x = !(a->enc_flags & NK_ENC_NO_INPUT_XYZ); p->inc_d = !(a->enc_flags & NK_ENC_NO_INPUT_DIR);
+    p->lin_x = (a->enc_flags & NK_ENC_LINEAR_XYZ) != 0; p->lin_d = (a->enc_flags & NK_ENC_LINEAR_DIR) != 0;
+    if ((!p->inc_x && p->Lx == 0) || (!p->inc_d && p->Ld == 0 && !p->no_dirs))
+        NK_FAIL(NK_ERR_UNSUPPORTED, "an encoding without the raw input needs at least one frequency");
+    // torch.linspace(1, 2^(L-1), L): step in float32 as torch computes it (a single element is the start)
+    p->end_x = p->Lx > 0 ? (float)(1 << (p->Lx - 1)) : 1.0f; p->step_x = p->Lx > 1 ? (p->end_x - 1.0f) / (float)(p->Lx - 1) : 0.0f;
+    p->end_d = p->Ld > 0 ? (float)(1 << (p->Ld - 1)) : 1.0f; p->step_d = p->Ld > 1 ? (p->end_d - 1.0f) / (float)(p->Ld - 1) : 0.0f;
+    const int in_xyz = 3 * p->inc_x + 6 * p->Lx, in_dir = 3 * p->inc_d + 6 * p->Ld;
     const int L_ALPHA = D, L_FEAT = D + 1, L_VIEWS = D + 2, L_RGB = D + 3;
 
     // shapes and forward segments

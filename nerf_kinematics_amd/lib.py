@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NK_LIB") or os.path.join(_HERE, "libnerfkin.so")
 
 NK_LINEAGE_RUN_NERF = 0
+NK_ENC_NO_INPUT_XYZ, NK_ENC_NO_INPUT_DIR, NK_ENC_LINEAR_XYZ, NK_ENC_LINEAR_DIR = 1, 2, 4, 8
 NK_LINEAGE_FLEXIBLE = 1
 
 # nk_render_rays_bwd runs the weight-gradient products of both networks in one shared launch up to
@@ -25,12 +26,12 @@ ACT_FORMATS = {"bf16": 0, "fp8": 1, "fp8bf8": 2}
 STREAM_STRATIFIED, STREAM_PDF, STREAM_NOISE_COARSE, STREAM_NOISE_FINE, STREAM_PIXELS = 0, 1, 2, 3, 4
 
 
-ABI_VERSION = 102          # nk_version() of the library these ctypes declarations describe
+ABI_VERSION = 103          # nk_version() of the library these ctypes declarations describe
 
 
 class NkArch(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("depth", "width", "skip", "dir_width", "n_freq_xyz", "n_freq_dir",
-                                         "relu_first", "relu_feat", "lineage", "no_viewdirs")]
+                                         "relu_first", "relu_feat", "lineage", "no_viewdirs", "enc_flags")]
 
 
 class NkStepState(C.Structure):
@@ -108,8 +109,8 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    # the structs above mirror include/nerf_kinematics.h of ONE library version (nk_arch grew a field in
-    # 102); a library built from other sources would read them wrongly.  NK_LIB (a developer comparing two
+    # the structs above mirror include/nerf_kinematics.h of ONE library version (nk_arch grew fields in
+    # 102 and 103); a library built from other sources would read them wrongly.  NK_LIB (a developer comparing two
     # builds) takes the responsibility itself.
     if lib.nk_version() != ABI_VERSION and "NK_LIB" not in os.environ:
         raise ImportError(f"{LIB_PATH} reports version {lib.nk_version()}, these bindings are for {ABI_VERSION}: "

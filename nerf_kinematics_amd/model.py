@@ -40,20 +40,30 @@ class Arch:
     relu_feat: bool = False
     lineage: str = "run_nerf"
     use_viewdirs: bool = True
+    # include_input_xyz / _dir, log_sampling_xyz / _dir of the models block (config.yml:21-24)
+    include_input_xyz: bool = True
+    include_input_dir: bool = True
+    log_sampling_xyz: bool = True
+    log_sampling_dir: bool = True
 
     @property
     def in_xyz(self) -> int:
-        return 3 + 6 * self.n_freq_xyz
+        return (3 if self.include_input_xyz else 0) + 6 * self.n_freq_xyz
 
     @property
     def in_dir(self) -> int:
-        return 3 + 6 * self.n_freq_dir
+        return (3 if self.include_input_dir else 0) + 6 * self.n_freq_dir
+
+    @property
+    def enc_flags(self) -> int:
+        return ((0 if self.include_input_xyz else _lib.NK_ENC_NO_INPUT_XYZ) | (0 if self.include_input_dir else _lib.NK_ENC_NO_INPUT_DIR)
+                | (0 if self.log_sampling_xyz else _lib.NK_ENC_LINEAR_XYZ) | (0 if self.log_sampling_dir else _lib.NK_ENC_LINEAR_DIR))
 
     def to_c(self) -> _lib.NkArch:
         return _lib.NkArch(self.depth, self.width, self.skip, self.dir_width, self.n_freq_xyz, self.n_freq_dir,
                            int(self.relu_first), int(self.relu_feat),
                            _lib.NK_LINEAGE_FLEXIBLE if self.lineage == "flexible" else _lib.NK_LINEAGE_RUN_NERF,
-                           int(not self.use_viewdirs))
+                           int(not self.use_viewdirs), self.enc_flags)
 
     def param_shapes(self) -> List[Tuple[str, Tuple[int, int]]]:
         """[(module name, (out, in))] in state-dict order."""
@@ -91,6 +101,10 @@ class Arch:
         lx = int(model_cfg.get("num_encoding_fn_xyz", 10))
         ld = int(model_cfg.get("num_encoding_fn_dir", 4))
         vd = bool(model_cfg.get("use_viewdirs", True))
+        enc = dict(include_input_xyz=bool(model_cfg.get("include_input_xyz", True)),
+                   include_input_dir=bool(model_cfg.get("include_input_dir", True)),
+                   log_sampling_xyz=bool(model_cfg.get("log_sampling_xyz", True)),
+                   log_sampling_dir=bool(model_cfg.get("log_sampling_dir", True)))
         if state_dict is not None:      # a stored network says itself whether it has a direction branch
             vd = not any(k in state_dict for k in ("fc_out.weight", "output_linear.weight"))
         if typ == "FlexibleNeRFModel":
@@ -109,12 +123,12 @@ class Arch:
                               "honoured (the reference trains 4 trunk layers whatever they say); building 4 layers. "
                               "Set honour_num_layers: true in the model block to build the depth named.", stacklevel=2)
             return Arch(depth=depth, width=W, skip=-1, dir_width=W // 2, n_freq_xyz=lx, n_freq_dir=ld,
-                        relu_first=False, relu_feat=True, lineage="flexible", use_viewdirs=vd)
+                        relu_first=False, relu_feat=True, lineage="flexible", use_viewdirs=vd, **enc)
         if typ in ("NeRF", "run_nerf"):
             D = int(model_cfg.get("num_layers", 8))
             return Arch(depth=D, width=W, skip=int(model_cfg.get("skip", 4 if D > 5 else -1)), dir_width=W // 2,
                         n_freq_xyz=lx, n_freq_dir=ld, relu_first=True, relu_feat=False, lineage="run_nerf",
-                        use_viewdirs=vd)
+                        use_viewdirs=vd, **enc)
         raise ValueError(f"unknown model type {typ!r}")
 
 

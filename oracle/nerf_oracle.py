@@ -210,14 +210,18 @@ class Arch:
     relu_feat: bool = False
     lineage: str = "run_nerf"   # or "flexible"
     use_viewdirs: bool = True
+    include_input_xyz: bool = True      # config.yml:21-24: gamma() starts with the raw 3-vector ...
+    include_input_dir: bool = True
+    log_sampling_xyz: bool = True       # ... frequencies 2^l (True) or linspace(1, 2^(L-1), L) (False)
+    log_sampling_dir: bool = True
 
     @property
     def in_xyz(self) -> int:
-        return 3 + 6 * self.n_freq_xyz
+        return (3 if self.include_input_xyz else 0) + 6 * self.n_freq_xyz
 
     @property
     def in_dir(self) -> int:
-        return 3 + 6 * self.n_freq_dir
+        return (3 if self.include_input_dir else 0) + 6 * self.n_freq_dir
 
     def param_shapes(self):
         """[(name, (out, in))] in flat/state-dict order (weight then bias for each)."""
@@ -478,11 +482,12 @@ def _run_net(net: NeRFNet, ray_batch: torch.Tensor, z: torch.Tensor) -> torch.Te
     o, d = ray_batch[:, 0:3], ray_batch[:, 3:6]
     pts = o[:, None, :] + d[:, None, :] * z[..., None]
     R, n = z.shape
-    x_enc = positional_encoding(pts.reshape(-1, 3), a.n_freq_xyz)
+    x_enc = positional_encoding(pts.reshape(-1, 3), a.n_freq_xyz, a.include_input_xyz, a.log_sampling_xyz)
     d_enc = None
     if a.use_viewdirs:
         vd = ray_batch[:, 8:11]
-        d_enc = positional_encoding(vd[:, None, :].expand(R, n, 3).reshape(-1, 3), a.n_freq_dir)
+        d_enc = positional_encoding(vd[:, None, :].expand(R, n, 3).reshape(-1, 3), a.n_freq_dir, a.include_input_dir,
+                                    a.log_sampling_dir)
     return net(x_enc, d_enc).reshape(R, n, 4)
 
 

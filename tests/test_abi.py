@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in the header but not exported"
         assert s in lib.SIGNATURES, f"{s} has no ctypes prototype"
-    assert L.nk_version() == lib.ABI_VERSION == 102
+    assert L.nk_version() == lib.ABI_VERSION == 103
 
 
 def test_parameter_counts_match_the_reference_checkpoints():

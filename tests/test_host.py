@@ -119,6 +119,31 @@ def test_use_viewdirs_false_builds_networks_without_the_direction_branch(golden_
     assert ckpt.arch_for_state_dict(dict(cfg["models"]["coarse"], use_viewdirs=True), sd) == arch
 
 
+def test_encoding_variants_reach_the_network_description(golden_dir, tmp_path):
+    """include_input_* / log_sampling_* of the models block (config.yml:21-24): input widths, the C
+    struct's flag bits, and the depth / frequency detection from a stored network."""
+    from nerf_kinematics_amd import lib as nklib
+    over = {"models": {"coarse": {"include_input_xyz": False, "log_sampling_dir": False},
+                       "fine": {"include_input_dir": False, "log_sampling_xyz": False}}}
+    cfg = config_mod.load_config(os.path.join(golden_dir, "lego-lowres3_config.yml"), over)
+    ac, af = Arch.from_config(cfg["models"]["coarse"]), Arch.from_config(cfg["models"]["fine"])
+    assert (ac.in_xyz, ac.in_dir, af.in_xyz, af.in_dir) == (60, 27, 63, 24)
+    assert ac.to_c().enc_flags == nklib.NK_ENC_NO_INPUT_XYZ | nklib.NK_ENC_LINEAR_DIR
+    assert af.to_c().enc_flags == nklib.NK_ENC_NO_INPUT_DIR | nklib.NK_ENC_LINEAR_XYZ
+    assert ARCH_LEGO_CKPT.to_c().enc_flags == 0
+    assert dict(ac.param_shapes())["layer1"] == (128, 60) and dict(af.param_shapes())["layers_dir.0"] == (64, 128 + 24)
+    assert ac.num_params() == ARCH_LEGO_CKPT.num_params() - 3 * 128 and af.num_params() == ARCH_LEGO_CKPT.num_params() - 3 * 64
+    L = nklib.load()
+    assert L.nk_num_params(ac.to_c()) == ac.num_params() and L.nk_num_params(af.to_c()) == af.num_params()
+    bad = ac.to_c(); bad.enc_flags = 64
+    assert L.nk_num_params(bad) == -1 and b"enc_flags" in L.nk_last_error()
+    # a stored network: the frequency count follows from the first layer's width and the block's switch
+    sd = ckpt.split_flat(af, torch.zeros(af.num_params()))
+    assert ckpt.arch_for_state_dict(cfg["models"]["fine"], sd) == af
+    sd = ckpt.split_flat(ac, torch.zeros(ac.num_params()))
+    assert ckpt.arch_for_state_dict(cfg["models"]["coarse"], sd) == ac
+
+
 def test_config_round_trip(golden_dir, tmp_path):
     cfg = config_mod.load_config(os.path.join(golden_dir, "wheel_robot6_config.yml"))
     config_mod.dump_config(cfg, str(tmp_path / "config.yml"))

@@ -1,5 +1,5 @@
 """Randomised parity sweep of render_rays against the oracle (dev tool): random network shapes (both
-lineages, with and without view directions, depth, skip, encoding lengths), sample counts, ray
+lineages, with and without view directions, depth, skip, encoding lengths and variants), sample counts, ray
 counts, flags and saved-tensor formats; compares the rgb and opacity maps of a training call and the
 gradient of both networks with the bf16-emulating oracle (which emulates the 8-bit formats too).
 
@@ -19,7 +19,7 @@ dev = torch.device("cuda:0")
 
 def oarch(a):
     return O.Arch(a.depth, a.width, a.skip, a.dir_width, a.n_freq_xyz, a.n_freq_dir, a.relu_first, a.relu_feat, a.lineage,
-                  a.use_viewdirs)
+                  a.use_viewdirs, a.include_input_xyz, a.include_input_dir, a.log_sampling_xyz, a.log_sampling_dir)
 
 
 def random_arch():
@@ -28,7 +28,9 @@ def random_arch():
     D = int(rng.integers(2, 9))
     skip = -1 if lineage == "flexible" or D < 3 or rng.random() < 0.3 else int(rng.integers(0, D - 1))
     return nk.Arch(D, W, skip, W // 2, int(rng.integers(1, 11)), int(rng.integers(1, 5)), bool(rng.integers(0, 2)),
-                   bool(rng.integers(0, 2)), lineage, use_viewdirs=bool(rng.random() < 0.7))
+                   bool(rng.integers(0, 2)), lineage, use_viewdirs=bool(rng.random() < 0.7),
+                   include_input_xyz=bool(rng.random() < 0.7), include_input_dir=bool(rng.random() < 0.7),
+                   log_sampling_xyz=bool(rng.random() < 0.7), log_sampling_dir=bool(rng.random() < 0.7))
 
 
 bad = 0
@@ -74,7 +76,7 @@ for case in range(cases):
             off += o
     target = torch.rand(R, 3, generator=g)
     tag = (f"case {case}: coarse {arch_c.depth}x{arch_c.width} {arch_c.lineage} skip {arch_c.skip} L {arch_c.n_freq_xyz}/{arch_c.n_freq_dir} "
-           f"dirs {int(arch_c.use_viewdirs)} | fine {arch_f.depth}x{arch_f.width} {arch_f.lineage} skip {arch_f.skip} dirs {int(arch_f.use_viewdirs)} "
+           f"dirs {int(arch_c.use_viewdirs)} enc {arch_c.enc_flags} | fine {arch_f.depth}x{arch_f.width} {arch_f.lineage} skip {arch_f.skip} dirs {int(arch_f.use_viewdirs)} "
            f"| R {R} Nc {Nc} Nf {Nf} cols {rb.shape[1]} ndc {int(ndc)} {fmt} {kw}")
     try:
         c = nk.NeRFModel(arch_c, fc.to(dev)); f = nk.NeRFModel(arch_f, ff.to(dev)) if Nf > 0 else None
